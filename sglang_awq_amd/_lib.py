@@ -1,0 +1,98 @@
+"""ctypes binding of lib/libawq_hip.so (the C ABI declared in include/awq_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this raises.  `build()`
+compiles it in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import threading
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_PKG, "csrc")
+LIB_PATH = os.path.join(_PKG, "lib", "libawq_hip.so")
+
+# every symbol include/awq_hip.h declares
+EXPORTS = (
+    "awq_hip_abi_version",
+    "awq_hip_build_info",
+    "awq_hip_status_string",
+    "awq_dequantize",
+    "awq_gemm_workspace_bytes",
+    "awq_gemm",
+    "awq_gemm_ex",
+)
+ABI_VERSION = 1
+
+DTYPE_F16, DTYPE_BF16, DTYPE_F32 = 0, 1, 2
+GEMM_AUTO, GEMM_GENERIC, GEMM_SKINNY, GEMM_TILED = 0, 1, 2, 3
+
+_lock = threading.Lock()
+_lib = None
+
+
+class AwqHipError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources into lib/libawq_hip.so (make decides what is stale)."""
+    cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else [])
+    res = subprocess.run(cmd, capture_output=not verbose, text=True)
+    if res.returncode != 0:
+        raise AwqHipError(f"building libawq_hip.so failed:\n{res.stdout}\n{res.stderr}")
+    if not os.path.exists(LIB_PATH):
+        raise AwqHipError(f"make succeeded but {LIB_PATH} is missing")
+    return LIB_PATH
+
+
+def _bind(L):
+    i64, vp, ci, sz = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    L.awq_hip_abi_version.argtypes = []
+    L.awq_hip_abi_version.restype = ci
+    L.awq_hip_build_info.argtypes = []
+    L.awq_hip_build_info.restype = ctypes.c_char_p
+    L.awq_hip_status_string.argtypes = [ci]
+    L.awq_hip_status_string.restype = ctypes.c_char_p
+    L.awq_dequantize.argtypes = [vp, vp, vp, vp, i64, i64, i64, ci, vp]
+    L.awq_dequantize.restype = ci
+    L.awq_gemm_workspace_bytes.argtypes = [i64, i64, i64, i64, ci]
+    L.awq_gemm_workspace_bytes.restype = sz
+    L.awq_gemm.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, sz, i64, i64, i64, i64, ci, ci, vp]
+    L.awq_gemm.restype = ci
+    L.awq_gemm_ex.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, sz, i64, i64, i64, i64, ci, ci, ci, i64, vp]
+    L.awq_gemm_ex.restype = ci
+
+
+def load():
+    """Load (once) and return the ctypes library; raises AwqHipError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise AwqHipError(
+                    f"{LIB_PATH} not found: the HIP extension is not built. Run "
+                    "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C sglang_awq_amd/csrc`). "
+                    "There is no CPU fallback for the AWQ ops.")
+            try:
+                L = ctypes.CDLL(LIB_PATH)
+            except OSError as e:
+                raise AwqHipError(f"cannot load {LIB_PATH}: {e}") from e
+            missing = [s for s in EXPORTS if not hasattr(L, s)]
+            if missing:
+                raise AwqHipError(f"{LIB_PATH} lacks symbols {missing}")
+            _bind(L)
+            if L.awq_hip_abi_version() != ABI_VERSION:
+                raise AwqHipError(f"ABI version {L.awq_hip_abi_version()} != expected {ABI_VERSION}; rebuild")
+            _lib = L
+    return _lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        msg = load().awq_hip_status_string(status).decode()
+        raise AwqHipError(f"{what} failed: {msg} (status {status})")

@@ -1,0 +1,143 @@
+"""AWQ quantization config and linear method for MI355X.
+
+Counterpart of `AWQConfig` / `AWQLinearMethod` in the reference
+(python/sglang/srt/layers/quantization/awq.py:89-179, :352-451): same constructor arguments, same
+parameter names, shapes and legality checks, same three-method plugin interface — so a layer built
+by the reference's `LinearBase` machinery can use it unchanged.  What differs is `apply()`:
+
+  reference   awq_dequantize(...) -> full [K, N] fp16 temp -> torch.matmul -> add_(bias)
+              (every decode step re-materialises every weight matrix, ~8.7x the bytes at M = 1)
+  here        one fused gfx950 launch (`awq_linear`: int4 tiles are dequantised in registers and
+              fed to MFMA; bias added in the epilogue with the reference's two roundings)
+
+`apply_mode="dequant_matmul"` keeps the reference's two-step structure on top of this package's
+`awq_dequantize` op (useful as an A/B baseline and for M beyond the fused kernels' sweet spot).
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Dict, List, Optional
+
+import torch
+
+from .base_config import LinearMethodBase, QuantizationConfig, QuantizeMethodBase
+from .parameter import GroupQuantScaleParameter, PackedvLLMParameter
+
+
+def is_layer_skipped_awq(prefix: str, modules_to_not_convert: List[str]) -> bool:
+    return any(module_name in prefix for module_name in modules_to_not_convert)
+
+
+class AWQConfig(QuantizationConfig):
+    """Config class for AWQ (awq.py:89-179).  Only 4-bit weights are supported."""
+
+    def __init__(self, weight_bits: int, group_size: int, zero_point: bool,
+                 modules_to_not_convert: Optional[List[str]] = None) -> None:
+        super().__init__()
+        self.weight_bits = weight_bits
+        self.group_size = group_size
+        self.zero_point = zero_point
+        self.modules_to_not_convert = modules_to_not_convert or []
+        if self.weight_bits != 4:
+            raise ValueError("Currently, only 4-bit weight quantization is supported for "
+                             f"AWQ, but got {self.weight_bits} bits.")
+        self.pack_factor = 32 // self.weight_bits
+
+    def __repr__(self) -> str:
+        return (f"AWQConfig(weight_bits={self.weight_bits}, group_size={self.group_size}, "
+                f"zero_point={self.zero_point}, modules_to_not_convert={self.modules_to_not_convert})")
+
+    def get_scaled_act_names(self) -> List[str]:
+        return []
+
+    def get_name(self) -> str:
+        return "awq"
+
+    def get_supported_act_dtypes(self) -> List[torch.dtype]:
+        # the reference lists fp16 only off-NPU (awq.py:129-130); the gfx950 kernels also take bf16
+        return [torch.float16, torch.bfloat16]
+
+    @classmethod
+    def get_min_capability(cls) -> int:
+        return 75
+
+    @staticmethod
+    def get_config_filenames() -> List[str]:
+        return ["quant_config.json", "quantize_config.json"]
+
+    @classmethod
+    def from_config(cls, config: Dict[str, Any]) -> "AWQConfig":
+        weight_bits = cls.get_from_keys(config, ["w_bit", "bits"])
+        group_size = cls.get_from_keys(config, ["q_group_size", "group_size"])
+        zero_point = cls.get_from_keys(config, ["zero_point"])
+        modules_to_not_convert = cls.get_from_keys_or(config, ["modules_to_not_convert"], None)
+        return cls(weight_bits, group_size, zero_point, modules_to_not_convert)
+
+    def get_quant_method(self, layer: torch.nn.Module, prefix: str) -> Optional[QuantizeMethodBase]:
+        from .linear import LinearBase, UnquantizedLinearMethod
+
+        if isinstance(layer, LinearBase):
+            if is_layer_skipped_awq(prefix, self.modules_to_not_convert):
+                return UnquantizedLinearMethod()
+            return AWQLinearMethod(self)
+        return None
+
+
+class AWQLinearMethod(LinearMethodBase):
+    """Linear method for AWQ (awq.py:352-451)."""
+
+    def __init__(self, quant_config: AWQConfig, apply_mode: Optional[str] = None):
+        self.quant_config = quant_config
+        mode = apply_mode or os.environ.get("SGLANG_AWQ_AMD_APPLY", "fused")
+        if mode not in ("fused", "dequant_matmul"):
+            raise ValueError(f"apply_mode must be 'fused' or 'dequant_matmul', got {mode!r}")
+        self.apply_mode = mode
+
+    def create_weights(self, layer: torch.nn.Module, input_size_per_partition: int,
+                       output_partition_sizes: List[int], input_size: int, output_size: int,
+                       params_dtype: torch.dtype, **extra_weight_attrs):
+        group_size = self.quant_config.group_size
+        if group_size == -1:
+            group_size = input_size_per_partition
+        if input_size_per_partition % group_size != 0:
+            raise ValueError("The input size is not aligned with the quantized weight shape. "
+                             "This can be caused by too large tensor parallel size.")
+        output_size_per_partition = sum(output_partition_sizes)
+        if output_size_per_partition % self.quant_config.pack_factor != 0:
+            raise ValueError("The output size is not aligned with the quantized weight shape. "
+                             "This can be caused by too large tensor parallel size.")
+
+        weight_loader = extra_weight_attrs.get("weight_loader")
+        pf = self.quant_config.pack_factor
+        qweight = PackedvLLMParameter(
+            data=torch.empty(input_size_per_partition, output_size_per_partition // pf, dtype=torch.int32),
+            input_dim=0, output_dim=1, packed_dim=1, packed_factor=pf, weight_loader=weight_loader)
+        qzeros = PackedvLLMParameter(
+            data=torch.empty(input_size_per_partition // group_size, output_size_per_partition // pf, dtype=torch.int32),
+            input_dim=0, output_dim=1, packed_dim=1, packed_factor=pf, weight_loader=weight_loader)
+        scales = GroupQuantScaleParameter(
+            data=torch.empty(input_size_per_partition // group_size, output_size_per_partition, dtype=params_dtype),
+            input_dim=0, output_dim=1, weight_loader=weight_loader)
+        layer.register_parameter("qweight", qweight)
+        layer.register_parameter("qzeros", qzeros)
+        layer.register_parameter("scales", scales)
+
+    def process_weights_after_loading(self, layer: torch.nn.Module) -> None:
+        # the kernels consume the on-disk AutoAWQ layout directly: no repack (awq.py:429-432)
+        layer.qweight = torch.nn.Parameter(layer.qweight.data, requires_grad=False)
+        layer.qzeros = torch.nn.Parameter(layer.qzeros.data, requires_grad=False)
+        layer.scales = torch.nn.Parameter(layer.scales.data, requires_grad=False)
+
+    def apply(self, layer: torch.nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        from . import ops
+
+        qweight, scales, qzeros = layer.qweight, layer.scales, layer.qzeros
+        out_shape = x.shape[:-1] + (qweight.shape[-1] * self.quant_config.pack_factor,)
+        reshaped_x = x.reshape(-1, x.shape[-1])
+        if self.apply_mode == "fused":
+            out = ops.awq_linear(reshaped_x, qweight, scales, qzeros, bias)
+        else:
+            out = torch.matmul(reshaped_x, ops.awq_dequantize(qweight, scales, qzeros))
+            if bias is not None:
+                out.add_(bias)
+        return out.reshape(out_shape)

@@ -1,0 +1,104 @@
+// extern "C" entry points declared in include/awq_hip.h: argument validation, variant choice,
+// launch.  No allocation, no synchronisation, no global mutable state beyond a once-only kernel
+// attribute in the skinny launcher.
+#include "awq_kernels.h"
+
+namespace {
+
+using namespace awq;
+
+int check_common(const void* qweight, const void* scales, const void* qzeros, int64_t K, int64_t N, int64_t g, int dtype) {
+  if (!qweight || !scales || !qzeros) return AWQ_ERR_NULL_POINTER;
+  if (dtype != AWQ_DTYPE_F16 && dtype != AWQ_DTYPE_BF16 && dtype != AWQ_DTYPE_F32) return AWQ_ERR_BAD_DTYPE;
+  if (K <= 0 || N <= 0 || g <= 0 || N % 8 != 0 || K % g != 0) return AWQ_ERR_BAD_SHAPE;
+  if (K > INT32_MAX / 2 || N > INT32_MAX / 2 || (K / 8) * N > (int64_t)INT32_MAX * 4) return AWQ_ERR_BAD_SHAPE;
+  // scales rows are read and outputs written 16 bytes at a time (as the reference op does,
+  // awq_kernel.cu:142,161); qweight / qzeros words 4 bytes at a time in the generic paths.
+  if ((((uintptr_t)scales) & 15) || (((uintptr_t)qweight) & 3) || (((uintptr_t)qzeros) & 3)) return AWQ_ERR_MISALIGNED;
+  return AWQ_OK;
+}
+
+bool pow2_le32(int v) { return v >= 1 && v <= 32 && (v & (v - 1)) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int awq_hip_abi_version(void) { return AWQ_HIP_ABI_VERSION; }
+
+const char* awq_hip_build_info(void) {
+  return "sglang_awq_amd libawq_hip: gfx950 (CDNA4, wave64), HIP " __VERSION__;
+}
+
+const char* awq_hip_status_string(int s) {
+  switch (s) {
+    case AWQ_OK: return "ok";
+    case AWQ_ERR_NULL_POINTER: return "null pointer";
+    case AWQ_ERR_BAD_SHAPE: return "bad shape (need N % 8 == 0, K % group_size == 0, positive dims, ldx >= K)";
+    case AWQ_ERR_BAD_DTYPE: return "bad dtype (0 = fp16, 1 = bf16, 2 = fp32)";
+    case AWQ_ERR_BAD_SPLIT_K: return "split_k_iters must be a power of two in [1, 32]";
+    case AWQ_ERR_WORKSPACE: return "workspace missing or smaller than awq_gemm_workspace_bytes()";
+    case AWQ_ERR_MISALIGNED: return "pointer not sufficiently aligned (16 bytes for scales / x / y / workspace)";
+    case AWQ_ERR_BAD_VARIANT: return "requested kernel variant cannot run this shape / dtype";
+    case AWQ_ERR_LAUNCH: return "kernel launch failed (hipGetLastError)";
+    default: return "unknown awq status";
+  }
+}
+
+int awq_dequantize(const int32_t* qweight, const void* scales, const int32_t* qzeros, void* out, int64_t K, int64_t N,
+                   int64_t group_size, int dtype, void* stream) {
+  int rc = check_common(qweight, scales, qzeros, K, N, group_size, dtype);
+  if (rc) return rc;
+  if (!out) return AWQ_ERR_NULL_POINTER;
+  if (((uintptr_t)out) & 15) return AWQ_ERR_MISALIGNED;
+  return launch_dequantize(qweight, scales, qzeros, out, K, N, group_size, dtype, (hipStream_t)stream);
+}
+
+size_t awq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t group_size, int dtype) {
+  (void)group_size;
+  (void)dtype;
+  if (M <= 0 || K <= 0 || N <= 0) return 4096;
+  return skinny_workspace_bytes(M, K, N);
+}
+
+int awq_gemm_ex(const void* x, int64_t ldx, const int32_t* qweight, const void* scales, const int32_t* qzeros,
+                const void* bias, void* y, void* workspace, size_t workspace_bytes, int64_t M, int64_t K, int64_t N,
+                int64_t group_size, int dtype, int split_k_iters, int variant, int64_t tune, void* stream) {
+  int rc = check_common(qweight, scales, qzeros, K, N, group_size, dtype);
+  if (rc) return rc;
+  if (M < 0 || ldx < K || M > INT32_MAX / 2) return AWQ_ERR_BAD_SHAPE;
+  if (!pow2_le32(split_k_iters)) return AWQ_ERR_BAD_SPLIT_K;
+  if (M == 0) return AWQ_OK;
+  if (!x || !y) return AWQ_ERR_NULL_POINTER;
+  const int eb = dtype == AWQ_DTYPE_F32 ? 4 : 2;
+  if ((((uintptr_t)x) | ((uintptr_t)y)) & (uintptr_t)(eb - 1)) return AWQ_ERR_MISALIGNED;
+
+  GemmArgs a;
+  a.x = x; a.ldx = ldx; a.qweight = qweight; a.scales = scales; a.qzeros = qzeros; a.bias = bias; a.y = y;
+  a.workspace = workspace; a.workspace_bytes = workspace_bytes;
+  a.M = (int)M; a.K = (int)K; a.N = (int)N; a.g = (int)group_size; a.dtype = dtype; a.tune = tune;
+  a.stream = (hipStream_t)stream;
+
+  switch (variant) {
+    case AWQ_GEMM_GENERIC: return launch_gemm_generic(a);
+    case AWQ_GEMM_SKINNY: return launch_gemm_skinny(a);
+    case AWQ_GEMM_TILED: return tiled_supported(a) ? launch_gemm_tiled(a) : AWQ_ERR_BAD_VARIANT;
+    case AWQ_GEMM_AUTO: break;
+    default: return AWQ_ERR_BAD_VARIANT;
+  }
+  if (skinny_supported(a)) {
+    if (!workspace || workspace_bytes < awq_gemm_workspace_bytes(M, K, N, group_size, dtype)) return AWQ_ERR_WORKSPACE;
+    return launch_gemm_skinny(a);
+  }
+  if (tiled_supported(a)) return launch_gemm_tiled(a);
+  return launch_gemm_generic(a);
+}
+
+int awq_gemm(const void* x, int64_t ldx, const int32_t* qweight, const void* scales, const int32_t* qzeros,
+             const void* bias, void* y, void* workspace, size_t workspace_bytes, int64_t M, int64_t K, int64_t N,
+             int64_t group_size, int dtype, int split_k_iters, void* stream) {
+  return awq_gemm_ex(x, ldx, qweight, scales, qzeros, bias, y, workspace, workspace_bytes, M, K, N, group_size, dtype,
+                     split_k_iters, AWQ_GEMM_AUTO, 0, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// Internal launcher declarations shared by the .hip translation units and the C ABI (awq_capi.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/awq_hip.h"
+
+namespace awq {
+
+struct GemmArgs {
+  const void* x;
+  int64_t ldx;
+  const int32_t* qweight;
+  const void* scales;
+  const int32_t* qzeros;
+  const void* bias;   // may be null
+  void* y;
+  void* workspace;
+  size_t workspace_bytes;
+  int M, K, N, g;
+  int dtype;
+  int64_t tune;
+  hipStream_t stream;
+};
+
+int launch_dequantize(const int32_t* qweight, const void* scales, const int32_t* qzeros, void* out, int64_t K,
+                      int64_t N, int64_t g, int dtype, hipStream_t stream);
+
+// generic VALU kernel: any legal shape / dtype
+int launch_gemm_generic(const GemmArgs& a);
+
+// skinny MFMA kernel (fp16 / bf16, M <= kSkinnyMaxM, N % 32 == 0, K % 32 == 0, g % 32 == 0)
+constexpr int kSkinnyMaxM = 32;
+bool skinny_supported(const GemmArgs& a);
+size_t skinny_workspace_bytes(int64_t M, int64_t K, int64_t N);
+int launch_gemm_skinny(const GemmArgs& a);
+
+// tiled MFMA kernel for large M (fp16 / bf16, N % 64 == 0, K % 32 == 0, g % 32 == 0)
+bool tiled_supported(const GemmArgs& a);
+int launch_gemm_tiled(const GemmArgs& a);
+
+}  // namespace awq

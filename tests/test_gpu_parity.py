@@ -1,0 +1,275 @@
+"""Parity of the HIP path (through the C ABI, via the torch ops) with the oracle, on a real MI355X.
+
+Bars (BASELINE.json north_star): awq_dequantize bit-exact; fused GEMM within 1e-3 absolute of the
+exact sum before the final rounding (plus the half-ulp the rounding itself adds) and, where outputs
+stay below 1 in magnitude, within 1e-3 of the reference result outright.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import awq_ref, c_oracle
+from sglang_awq_amd import _lib, synth
+from tests.util import TORCH_DT, assert_gemm_close, bits, to_np, to_torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sglang_awq_amd import ops as _ops   # raises if the HIP library is missing: no fallback
+
+    _lib.load()
+    return _ops
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _dev(*arrs):
+    return [to_torch(a, DEV) for a in arrs]
+
+
+# ------------------------------------------------------------------------------ awq_dequantize
+def test_dequantize_golden_small_bit_exact(ops):
+    z = np.load(os.path.join(GOLD, "awq_dequant_small.npz"))
+    for i in range(int(z["n_dequant"])):
+        qw, s, qz = z[f"dq{i}_qweight"], z[f"dq{i}_scales"], z[f"dq{i}_qzeros"]
+        out = to_np(ops.awq_dequantize(*_dev(qw, s, qz)))
+        assert out.shape == z[f"dq{i}_out"].shape
+        assert np.array_equal(bits(out), bits(z[f"dq{i}_out"])), f"case {i} {z[f'dq{i}_meta']} {z[f'dq{i}_dtype']}"
+    for i in range(int(z["n_verbatim"])):
+        qw, s, qz = z[f"verb{i}_qweight"], z[f"verb{i}_scales"], z[f"verb{i}_qzeros"]
+        out = to_np(ops.awq_dequantize(*_dev(qw, s, qz)))
+        assert np.array_equal(bits(out), bits(z[f"verb{i}_out"]))
+
+
+def test_dequantize_digests_reference_grids_and_baseline_shapes(ops):
+    """Every digest case: the reference's two test grids (g = K, g in {32, 64, 128}; fp16 + bf16) and the
+    BASELINE shapes incl. 4096 x 11008 g128, all three input families — sha256 of the output bytes."""
+    with open(os.path.join(GOLD, "digests.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        qw, s, qz = synth.make_awq_weights(c["K"], c["N"], c["g"], c["dtype"], c["family"], c["seed"])
+        out = ops.awq_dequantize(*_dev(qw, s, qz))
+        assert out.dtype == TORCH_DT[c["dtype"]] and tuple(out.shape) == (c["K"], c["N"])
+        assert _sha(to_np(out)) == c["out_sha256"], f"digest mismatch {c}"
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+def test_dequantize_ragged_shapes_vs_oracle(ops, dt):
+    # K not a multiple of the 32-row workgroup tile, packed columns not a multiple of 64, g = K,
+    # one group spanning several lanes' row blocks, a single packed column
+    for K, N, g in [(8, 8, 8), (40, 8, 8), (72, 520, 24), (100, 64, 100), (96, 1032, 32), (3, 16, 1), (130, 72, 65)]:
+        qw, s, qz = synth.make_awq_weights(K, N, g, dt, "F", seed=K * 7 + N)
+        out = to_np(ops.awq_dequantize(*_dev(qw, s, qz)))
+        want = awq_ref.awq_dequantize(qw, s, qz)
+        assert np.array_equal(bits(out), bits(want)), (K, N, g, dt)
+
+
+def test_dequantize_extreme_scales_bit_exact(ops):
+    """fp16 subnormal / tiny / huge scales: the product must round (and underflow) like the oracle."""
+    K, N, g = 64, 64, 32
+    qw, _, qz = synth.make_awq_weights(K, N, g, "f16", "F", seed=5)
+    raw = synth.rand_u32((K // g, N), 77, 9)
+    s = (raw & 0x7BFF).astype(np.uint16).view(np.float16)          # every finite non-negative half pattern
+    s[0, :8] = np.array([0, 6e-8, 1.2e-7, 6.1e-5, 6.104e-5, 65504, 4368, 1e-3], dtype=np.float16)
+    out = to_np(ops.awq_dequantize(*_dev(qw, s, qz)))
+    assert np.array_equal(bits(out), bits(awq_ref.awq_dequantize(qw, s, qz)))
+
+
+def test_dequantize_errors(ops):
+    qw, s, qz = _dev(*synth.make_awq_weights(128, 64, 32, "f16", "A", 1))
+    with pytest.raises(RuntimeError):
+        ops.awq_dequantize(qw.to(torch.int64), s, qz)
+    with pytest.raises(RuntimeError):
+        ops.awq_dequantize(qw, s[:, :-8], qz)
+    with pytest.raises(RuntimeError):
+        ops.awq_dequantize(qw, s, qz[:, :-1])
+    with pytest.raises(RuntimeError):
+        ops.awq_dequantize(qw.t().contiguous().t(), s, qz)            # non-contiguous
+    with pytest.raises(RuntimeError):
+        ops.awq_dequantize(qw, s.to(torch.float64), qz)
+
+
+# ------------------------------------------------------------------------------ awq_gemm
+def _gemm_case(ops, M, K, N, g, dt, family, seed, variant, tune=0, x_std=1.0, bias=False):
+    qw, s, qz = synth.make_awq_weights(K, N, g, dt, family, seed)
+    x = synth.make_activations(M, K, dt, family, seed, x_std=x_std)
+    b = synth.make_bias(N, dt, seed) if bias else None
+    dq, ds, dz, dx = _dev(qw, s, qz, x)
+    db = to_torch(b, DEV) if bias else None
+    y = to_np(ops.awq_gemm_variant(dx, dq, ds, dz, variant, tune, db))
+    _, exact = c_oracle.gemm(x, qw, s, qz, want_exact=True)
+    return y, exact, (qw, s, qz, x, b)
+
+
+def test_gemm_reference_triton_grid_fp32(ops):
+    """The reference's own GEMM test grid (fp32, K = 128, split-K 1 / 8) against its stored outputs."""
+    z = np.load(os.path.join(GOLD, "awq_gemm_triton_f32.npz"))
+    for i in range(int(z["n_cases"])):
+        M, K, N, g, sk = (int(v) for v in z[f"g{i}_meta"])
+        x, qw, s, qz = _dev(z[f"g{i}_x"], z[f"g{i}_qweight"], z[f"g{i}_scales"], z[f"g{i}_qzeros"])
+        y = to_np(ops.awq_gemm(x, qw, s, qz, sk))
+        assert y.dtype == np.float32 and y.shape == (M, N)
+        np.testing.assert_allclose(y, z[f"g{i}_triton"], atol=1e-1, rtol=1e-1)     # the reference's bar
+        np.testing.assert_allclose(y, z[f"g{i}_matmul"], atol=1e-3, rtol=1e-5)     # ours
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 7, 8, 13, 16])
+def test_gemm_skinny_vs_oracle(ops, dt, M):
+    for (K, N, g, tune) in [(256, 512, 128, 0), (512, 1056, 128, 1), (1024, 96, 64, 2), (384, 544, 32, 0),
+                            (512, 512, 128, 4), (2048, 1024, 128, (8 << 8) | 1), (4096, 512, 4096, 0)]:
+        y, exact, _ = _gemm_case(ops, M, K, N, g, dt, "A", seed=M * 1000 + K + N, variant=_lib.GEMM_SKINNY, tune=tune)
+        assert_gemm_close(y, exact, dt, what=f"skinny M={M} K={K} N={N} g={g} tune={tune} {dt}")
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+def test_gemm_generic_vs_oracle(ops, dt):
+    for (M, K, N, g) in [(1, 128, 8, 128), (5, 96, 40, 32), (9, 200, 520, 100), (33, 256, 72, 64), (4, 64, 1024, 64)]:
+        y, exact, _ = _gemm_case(ops, M, K, N, g, dt, "A", seed=M + K, variant=_lib.GEMM_GENERIC)
+        assert_gemm_close(y, exact, dt, what=f"generic {M} {K} {N} {g} {dt}")
+
+
+def test_gemm_auto_dispatch_all_m(ops):
+    K, N, g = 512, 1024, 128
+    for M in [1, 4, 16, 17, 32, 33, 64, 100, 256]:
+        qw, s, qz = synth.make_awq_weights(K, N, g, "f16", "A", M)
+        x = synth.make_activations(M, K, "f16", "A", M)
+        y = to_np(ops.awq_gemm(*_dev(x, qw, s, qz), 1))
+        _, exact = c_oracle.gemm(x, qw, s, qz, want_exact=True)
+        assert_gemm_close(y, exact, "f16", what=f"auto M={M}")
+
+
+def test_gemm_atol_1e3_on_unit_scale_outputs(ops):
+    """With |y| < 1 the fp16 output ulp is < 1e-3, so the north star's bar applies to the rounded
+    outputs directly: max |y_gpu - y_ref| <= 1e-3 against the correctly rounded oracle."""
+    for M in (1, 8, 16):
+        y, exact, (qw, s, qz, x, _) = _gemm_case(ops, M, 4096, 1024, 128, "f16", "A", seed=99 + M, variant=_lib.GEMM_AUTO, x_std=0.03)
+        ref = awq_ref.to_f64(awq_ref.from_f64(exact, "f16"), "f16")
+        assert np.abs(exact).max() < 1.0
+        assert np.abs(awq_ref.to_f64(y, "f16") - ref).max() <= 1e-3
+
+
+def test_gemm_one_hot_rows_reproduce_dequantize_bit_exact(ops):
+    """Size-independent property at the full BASELINE shape: x = e_k selects row k of W, every other
+    product is an exact zero, so awq_gemm must return awq_dequantize's row bit for bit."""
+    K, N, g = 4096, 11008, 128
+    qw, s, qz = _dev(*synth.make_awq_weights(K, N, g, "f16", "F", 4242))
+    W = ops.awq_dequantize(qw, s, qz)
+    rows = [0, 1, 127, 128, 2047, 2048, 4095, 31, 32, 33, 1000, 3000, 4064, 555, 77, 4094]
+    x = torch.zeros(len(rows), K, dtype=torch.float16, device=DEV)
+    for m, k in enumerate(rows):
+        x[m, k] = 1.0
+    for M in (1, 5, 16):
+        y = ops.awq_gemm(x[:M], qw, s, qz, 1)
+        assert torch.equal(y, W[rows[:M]]), f"M={M}"
+
+
+def test_gemm_full_size_column_sums(ops):
+    """x = ones at 4096 x 11008: y = column sums of W; checked against an fp64 sum of the GPU's own
+    (bit-exact, see above) dequantised weight."""
+    K, N, g = 4096, 11008, 128
+    qw, s, qz = _dev(*synth.make_awq_weights(K, N, g, "f16", "A", 1234))
+    W = ops.awq_dequantize(qw, s, qz)
+    exact = W.double().sum(0, keepdim=True).cpu().numpy()
+    x = torch.ones(1, K, dtype=torch.float16, device=DEV)
+    assert_gemm_close(to_np(ops.awq_gemm(x, qw, s, qz, 1)), exact, "f16", what="column sums")
+
+
+def test_gemm_deterministic_and_split_k_independent(ops):
+    qw, s, qz = _dev(*synth.make_awq_weights(4096, 2048, 128, "f16", "A", 7))
+    x = to_torch(synth.make_activations(3, 4096, "f16", "A", 7), DEV)
+    y0 = ops.awq_gemm(x, qw, s, qz, 1)
+    for sk in (1, 2, 8, 32):
+        for _ in range(3):
+            assert torch.equal(ops.awq_gemm(x, qw, s, qz, sk), y0)
+
+
+def test_gemm_bias_epilogue_two_roundings(ops):
+    for dt in ("f16", "bf16"):
+        qw, s, qz = synth.make_awq_weights(512, 1024, 128, dt, "A", 3)
+        x = synth.make_activations(4, 512, dt, "A", 3)
+        b = synth.make_bias(1024, dt, 3)
+        dq, ds, dz, dx, db = _dev(qw, s, qz, x, b)
+        y = ops.awq_gemm(dx, dq, ds, dz, 1)
+        yb = ops.awq_linear(dx, dq, ds, dz, db)
+        assert torch.equal(yb, y + db)          # torch's same-dtype add rounds once more, as add_ does
+        want = awq_ref.awq_linear_apply(x, qw, s, qz, b)
+        d = np.abs(awq_ref.to_f64(to_np(yb), dt) - awq_ref.to_f64(want, dt))
+        assert (d > 0).mean() < 0.02
+
+
+def test_gemm_strided_activation_slice(ops):
+    """Row-parallel ranks pass a K-slice of a wider activation (linear.py:1395-1399): ldx > K."""
+    qw, s, qz = _dev(*synth.make_awq_weights(512, 1024, 128, "f16", "A", 11))
+    xfull = to_torch(synth.make_activations(6, 2048, "f16", "A", 11), DEV)
+    xs = xfull[:, 512:1024]
+    assert not xs.is_contiguous()
+    assert torch.equal(ops.awq_gemm(xs, qw, s, qz, 1), ops.awq_gemm(xs.contiguous(), qw, s, qz, 1))
+
+
+def test_gemm_errors(ops):
+    qw, s, qz = _dev(*synth.make_awq_weights(128, 64, 32, "f16", "A", 1))
+    x = torch.ones(2, 128, dtype=torch.float16, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.awq_gemm(x, qw, s, qz, 3)
+    with pytest.raises(RuntimeError):
+        ops.awq_gemm(x, qw, s, qz, 64)
+    with pytest.raises(RuntimeError):
+        ops.awq_gemm(x[:, :64], qw, s, qz, 1)
+    with pytest.raises(RuntimeError):
+        ops.awq_gemm(x.float(), qw, s, qz, 1)
+    assert ops.awq_gemm(x[:0], qw, s, qz, 1).shape == (0, 64)
+
+
+def test_ops_are_graph_capturable(ops):
+    """The decode path replays captured graphs (model_runner.py:2765-2771): launch-only, no sync."""
+    qw, s, qz = _dev(*synth.make_awq_weights(1024, 1024, 128, "f16", "A", 21))
+    x = to_torch(synth.make_activations(1, 1024, "f16", "A", 21), DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        eager = ops.awq_gemm(x, qw, s, qz, 1)          # warm-up on the capture stream (workspace alloc)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        y = ops.awq_gemm(x, qw, s, qz, 1)
+        w = ops.awq_dequantize(qw, s, qz)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, eager)
+    assert torch.equal(w, ops.awq_dequantize(qw, s, qz))
+
+
+# ------------------------------------------------------------------------------ AWQLinearMethod
+def test_awq_linear_method_apply_matches_oracle(ops):
+    from sglang_awq_amd.awq import AWQConfig, AWQLinearMethod
+
+    cfg = AWQConfig(weight_bits=4, group_size=128, zero_point=True)
+    for mode in ("fused", "dequant_matmul"):
+        method = AWQLinearMethod(cfg, apply_mode=mode)
+        layer = torch.nn.Module()
+        method.create_weights(layer, 512, [768, 256], 512, 1024, torch.float16, weight_loader=None)
+        assert layer.qweight.shape == (512, 128) and layer.qzeros.shape == (4, 128) and layer.scales.shape == (4, 1024)
+        qw, s, qz = synth.make_awq_weights(512, 1024, 128, "f16", "A", 31)
+        layer.qweight.data.copy_(to_torch(qw)); layer.qzeros.data.copy_(to_torch(qz)); layer.scales.data.copy_(to_torch(s))
+        layer.to(DEV)
+        method.process_weights_after_loading(layer)
+        x = synth.make_activations(6, 512, "f16", "A", 31).reshape(2, 3, 512)
+        b = synth.make_bias(1024, "f16", 31)
+        y = method.apply(layer, to_torch(x, DEV), to_torch(b, DEV))
+        assert y.shape == (2, 3, 1024)
+        want = awq_ref.to_f64(awq_ref.awq_linear_apply(x, qw, s, qz, b), "f16")
+        got = awq_ref.to_f64(to_np(y), "f16")
+        from tests.util import ulp
+        assert np.all(np.abs(got - want) <= 1.01 * ulp(want, "f16")), mode

@@ -1,0 +1,137 @@
+"""CPU-side checks: the C-ABI library loads, exports exactly what include/awq_hip.h declares, rejects
+bad arguments before touching the GPU, and the host-side mirror of the reference interface behaves
+like the reference (shapes, errors).  No compute calls: there is no GPU here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from sglang_awq_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _lib.build()
+    return _lib.load()
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "awq_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(awq_[a-z_]+)\s*\(", text)))
+
+
+def test_header_and_export_list_agree(lib):
+    assert _header_functions() == sorted(_lib.EXPORTS)
+    for sym in _lib.EXPORTS:
+        assert hasattr(lib, sym), sym
+
+
+def test_shared_object_exports_symbols_with_c_linkage():
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    for sym in _lib.EXPORTS:
+        assert sym in names, f"{sym} not exported unmangled"
+
+
+def test_abi_version_and_strings(lib):
+    assert lib.awq_hip_abi_version() == _lib.ABI_VERSION
+    assert b"gfx950" in lib.awq_hip_build_info()
+    assert lib.awq_hip_status_string(0) == b"ok"
+    for code in (-1, -2, -3, -4, -5, -6, -7, -100):
+        assert lib.awq_hip_status_string(code) != lib.awq_hip_status_string(12345)
+
+
+def test_argument_validation_without_gpu(lib):
+    """Every rejection below returns before any HIP call."""
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.cast(buf, ctypes.c_void_p).value
+    p = (p + 15) & ~15
+    vp = ctypes.c_void_p
+    assert lib.awq_dequantize(None, vp(p), vp(p), vp(p), 128, 64, 128, 0, None) == -1
+    assert lib.awq_dequantize(vp(p), vp(p), vp(p), None, 128, 64, 128, 0, None) == -1
+    assert lib.awq_dequantize(vp(p), vp(p), vp(p), vp(p), 128, 60, 128, 0, None) == -2   # N % 8
+    assert lib.awq_dequantize(vp(p), vp(p), vp(p), vp(p), 100, 64, 64, 0, None) == -2    # K % g
+    assert lib.awq_dequantize(vp(p), vp(p), vp(p), vp(p), 0, 64, 64, 0, None) == -2
+    assert lib.awq_dequantize(vp(p), vp(p), vp(p), vp(p), 128, 64, 128, 7, None) == -3
+    assert lib.awq_dequantize(vp(p), vp(p + 2), vp(p), vp(p), 128, 64, 128, 0, None) == -6
+    g = lambda **kw: lib.awq_gemm(kw.get("x", vp(p)), kw.get("ldx", 128), vp(p), vp(p), vp(p), None, kw.get("y", vp(p)),
+                                  vp(p), 4096, kw.get("M", 1), 128, 64, 128, 0, kw.get("sk", 1), None)
+    assert g(sk=3) == -4
+    assert g(sk=64) == -4
+    assert g(ldx=64) == -2
+    assert g(x=None) == -1
+    assert g(M=0) == 0            # empty batch: nothing to launch
+    assert lib.awq_gemm_ex(vp(p), 128, vp(p), vp(p), vp(p), None, vp(p), vp(p), 4096, 1, 128, 64, 128, 0, 1, 99, 0, None) == -7
+
+
+def test_workspace_query(lib):
+    small = lib.awq_gemm_workspace_bytes(1, 4096, 11008, 128, 0)
+    assert 4096 <= small <= 4096 + (32 << 20)
+    assert lib.awq_gemm_workspace_bytes(2048, 4096, 11008, 128, 0) >= 4096
+    assert lib.awq_gemm_workspace_bytes(0, 0, 0, 128, 0) >= 0
+
+
+def test_ops_registered_with_reference_schema():
+    from sglang_awq_amd import ops  # noqa: F401
+
+    s = torch.ops.sgl_kernel.awq_dequantize.default._schema
+    assert [a.name for a in s.arguments] == ["qweight", "scales", "qzeros"]          # common_extension.cc:126
+    s = torch.ops.sgl_kernel.awq_gemm.default._schema
+    assert [a.name for a in s.arguments] == ["input", "qweight", "scales", "qzeros", "split_k_iters"]  # awq_triton.py:289-294
+
+
+def test_ops_have_no_cpu_fallback():
+    from sglang_awq_amd import ops
+
+    qw = torch.zeros(128, 8, dtype=torch.int32)
+    qz = torch.zeros(1, 8, dtype=torch.int32)
+    sc = torch.ones(1, 64, dtype=torch.float16)
+    with pytest.raises(NotImplementedError):
+        ops.awq_dequantize(qw, sc, qz)
+    with pytest.raises(NotImplementedError):
+        ops.awq_gemm(torch.ones(1, 128, dtype=torch.float16), qw, sc, qz, 1)
+
+
+def test_fake_impls_have_correct_arity_and_shapes():
+    from sglang_awq_amd import ops  # noqa: F401
+
+    qw = torch.empty(256, 16, dtype=torch.int32, device="meta")
+    qz = torch.empty(2, 16, dtype=torch.int32, device="meta")
+    sc = torch.empty(2, 128, dtype=torch.bfloat16, device="meta")
+    out = torch.ops.sgl_kernel.awq_dequantize(qw, sc, qz)
+    assert out.shape == (256, 128) and out.dtype == torch.bfloat16
+    x = torch.empty(5, 256, dtype=torch.bfloat16, device="meta")
+    y = torch.ops.sgl_kernel.awq_gemm(x, qw, sc, qz, 8)
+    assert y.shape == (5, 128) and y.dtype == torch.bfloat16
+
+
+def test_sgl_kernel_compat_install():
+    import sys
+
+    from sglang_awq_amd import sgl_kernel_compat
+
+    saved = sys.modules.pop("sgl_kernel", None)
+    try:
+        mod = sgl_kernel_compat.install()
+        import sgl_kernel
+
+        assert sgl_kernel is mod
+        assert callable(sgl_kernel.awq_dequantize) and callable(sgl_kernel.awq_gemm)
+    finally:
+        sys.modules.pop("sgl_kernel", None)
+        if saved is not None:
+            sys.modules["sgl_kernel"] = saved
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.AwqHipError, match="no CPU fallback"):
+        _lib.load()
