@@ -29,6 +29,15 @@ constexpr uint32_t kLoNib = 0x000f000fu;
 constexpr uint32_t kHiNib = 0x00f000f0u;
 constexpr uint32_t kMagicF16 = 0x64006400u;  // half2(1024, 1024)
 
+// (a & mask) | orv in ONE instruction.  gfx9-family VOP3 cannot encode two 32-bit literals, so hipcc
+// emits v_and + v_or for the literal form; with the mask in an SGPR and the OR value in a VGPR the
+// fused v_and_or_b32 is encodable (one constant-bus operand).
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t orv) {
+  uint32_t d;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(mask), "v"(orv));
+  return d;
+}
+
 __device__ __forceinline__ half2_t as_h2(uint32_t u) { return __builtin_bit_cast(half2_t, u); }
 __device__ __forceinline__ uint32_t as_u32(half2_t h) { return __builtin_bit_cast(uint32_t, h); }
 
@@ -52,10 +61,11 @@ __device__ __forceinline__ ZeroF16 make_zero_f16(uint32_t zw) {
 __device__ __forceinline__ void unpack_sub_f16(uint32_t w, const ZeroF16& z, half2_t (&d)[4]) {
   const half2_t sixteenth = {(half_t)0.0625f, (half_t)0.0625f};
   const uint32_t w8 = w >> 8;
-  d[0] = as_h2((w & kLoNib) | kMagicF16) - z.z01;
-  d[1] = __builtin_elementwise_fma(as_h2((w & kHiNib) | kMagicF16), sixteenth, -z.z23);
-  d[2] = as_h2((w8 & kLoNib) | kMagicF16) - z.z45;
-  d[3] = __builtin_elementwise_fma(as_h2((w8 & kHiNib) | kMagicF16), sixteenth, -z.z67);
+  const uint32_t magic = kMagicF16;
+  d[0] = as_h2(and_or(w, kLoNib, magic)) - z.z01;
+  d[1] = __builtin_elementwise_fma(as_h2(and_or(w, kHiNib, magic)), sixteenth, -z.z23);
+  d[2] = as_h2(and_or(w8, kLoNib, magic)) - z.z45;
+  d[3] = __builtin_elementwise_fma(as_h2(and_or(w8, kHiNib, magic)), sixteenth, -z.z67);
 }
 
 // Plain integer nibble of logical column j (used by the bf16 / fp32 / generic paths).

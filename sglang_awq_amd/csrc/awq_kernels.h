@@ -31,8 +31,8 @@ int launch_dequantize(const int32_t* qweight, const void* scales, const int32_t*
 // generic VALU kernel: any legal shape / dtype
 int launch_gemm_generic(const GemmArgs& a);
 
-// skinny MFMA kernel (fp16 / bf16, M <= kSkinnyMaxM, N % 32 == 0, K % 32 == 0, g % 32 == 0)
-constexpr int kSkinnyMaxM = 32;
+// skinny MFMA kernel (fp16 / bf16, M <= 16, N % 32 == 0, K % 32 == 0, g % 32 == 0)
+constexpr int kSkinnyMaxM = 16;
 bool skinny_supported(const GemmArgs& a);
 size_t skinny_workspace_bytes(int64_t M, int64_t K, int64_t N);
 int launch_gemm_skinny(const GemmArgs& a);

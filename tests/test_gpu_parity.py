@@ -126,8 +126,11 @@ def test_gemm_reference_triton_grid_fp32(ops):
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("M", [1, 2, 3, 4, 7, 8, 13, 16])
 def test_gemm_skinny_vs_oracle(ops, dt, M):
-    for (K, N, g, tune) in [(256, 512, 128, 0), (512, 1056, 128, 1), (1024, 96, 64, 2), (384, 544, 32, 0),
-                            (512, 512, 128, 4), (2048, 1024, 128, (8 << 8) | 1), (4096, 512, 4096, 0)]:
+    # tune bits 8-15 force the number of K-slices S (0 = heuristic): 1 slice (no hand-off), odd counts,
+    # more slices than k-steps / 4, ragged last column tile (N = 1056, 544, 96), g = 32 / 64 / K
+    for (K, N, g, tune) in [(256, 512, 128, 0), (512, 1056, 128, 1 << 8), (1024, 96, 64, 3 << 8), (384, 544, 32, 0),
+                            (512, 512, 128, 2 << 8), (2048, 1024, 128, 8 << 8), (4096, 512, 4096, 0),
+                            (2048, 512, 128, 200 << 8), (1056 * 2, 1024, 32, 5 << 8)]:
         y, exact, _ = _gemm_case(ops, M, K, N, g, dt, "A", seed=M * 1000 + K + N, variant=_lib.GEMM_SKINNY, tune=tune)
         assert_gemm_close(y, exact, dt, what=f"skinny M={M} K={K} N={N} g={g} tune={tune} {dt}")
 
@@ -272,4 +275,7 @@ def test_awq_linear_method_apply_matches_oracle(ops):
         want = awq_ref.to_f64(awq_ref.awq_linear_apply(x, qw, s, qz, b), "f16")
         got = awq_ref.to_f64(to_np(y), "f16")
         from tests.util import ulp
-        assert np.all(np.abs(got - want) <= 1.01 * ulp(want, "f16")), mode
+        # fused: one output ulp; dequant + vendor-BLAS matmul is third-party arithmetic (its fp32 sums
+        # are ordered differently), so a rounding-boundary flip before the bias add can cost a second ulp
+        tol = 1.01 if mode == "fused" else 2.02
+        assert np.all(np.abs(got - want) <= tol * ulp(want, "f16")), mode

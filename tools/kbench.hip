@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -109,6 +110,27 @@ __global__ __launch_bounds__(1024) void read_strip_pattern(const uint32_t* __res
   if (acc == 0x12345678u) *sink = acc;
 }
 
+// pattern 3: column strips with an XCD-aware strip assignment: blocks b and b+8 share an XCD (observed
+// round-robin dispatch), so strips that share 128-byte lines are given to blocks of equal b % 8.
+// W16 = 16-byte chunks per row owned by the workgroup (1 -> 32 columns, 2 -> 64 columns).
+template <int W16>
+__global__ __launch_bounds__(1024) void read_strip_xcd(const uint32_t* __restrict__ qw, int K, int C, int nstrips, uint32_t* sink) {
+  const int b = blockIdx.x;
+  const int per = (nstrips + 7) / 8;
+  const int strip = (b % 8) * per + b / 8;
+  uint32_t acc = 0;
+  if (strip < nstrips && (b / 8) < per) {
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+#pragma unroll
+      for (int u = 0; u < W16; ++u) {
+        u32x4 v = *(const u32x4*)(qw + (size_t)k * C + (strip * W16 + u) * 4);
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+      }
+    }
+  }
+  if (acc == 0x12345678u) *sink = acc;
+}
+
 static int cmd_read(int argc, char** argv) {
   const int K = 4096, C = 1376;
   const int sets = argc > 2 ? atoi(argv[2]) : 16;
@@ -138,6 +160,10 @@ static int cmd_read(int argc, char** argv) {
   time_it("gemv-pattern KT=2 (352 wg)", [&](uint32_t* b) { hipLaunchKernelGGL(read_gemv_pattern<2>, dim3(n_ct * 16), dim3(256), 0, st, b, K, C, n_ct, sink); });
   time_it("gemv-pattern KT=4 (176 wg)", [&](uint32_t* b) { hipLaunchKernelGGL(read_gemv_pattern<4>, dim3(n_ct * 8), dim3(256), 0, st, b, K, C, n_ct, sink); });
   time_it("strip-pattern 344 wg x 1024", [&](uint32_t* b) { hipLaunchKernelGGL(read_strip_pattern, dim3(C / 4), dim3(1024), 0, st, b, K, C, sink); });
+  time_it("strip-xcd 16B 344 wg x 1024", [&](uint32_t* b) { hipLaunchKernelGGL(read_strip_xcd<1>, dim3(344), dim3(1024), 0, st, b, K, C, 344, sink); });
+  time_it("strip-xcd 16B 344 wg x 512", [&](uint32_t* b) { hipLaunchKernelGGL(read_strip_xcd<1>, dim3(344), dim3(512), 0, st, b, K, C, 344, sink); });
+  time_it("strip-xcd 32B 176 wg x 1024", [&](uint32_t* b) { hipLaunchKernelGGL(read_strip_xcd<2>, dim3(176), dim3(1024), 0, st, b, K, C, 172, sink); });
+  time_it("strip-xcd 64B 88 wg x 1024", [&](uint32_t* b) { hipLaunchKernelGGL(read_strip_xcd<4>, dim3(88), dim3(1024), 0, st, b, K, C, 86, sink); });
   time_it("strip-pattern 344 wg x 512", [&](uint32_t* b) { hipLaunchKernelGGL(read_strip_pattern, dim3(C / 4), dim3(512), 0, st, b, K, C, sink); });
   return 0;
 }
@@ -218,6 +244,50 @@ static int cmd_gemm(int argc, char** argv) {
   return 0;
 }
 
+// one stamped launch (diagnostic build of the skinny kernel): per-workgroup phase times
+static int cmd_stamps(int argc, char** argv) {
+  if (argc < 8) { fprintf(stderr, "usage: kbench stamps M K N g dtype tune [sets]\n"); return 2; }
+  const int M = atoi(argv[2]), K = atoi(argv[3]), N = atoi(argv[4]), g = atoi(argv[5]), dtype = atoi(argv[6]);
+  long long tune = strtoll(argv[7], nullptr, 0);
+  if (((tune >> 16) & 7) == 0) tune |= 0x30000;
+  const int sets = argc > 8 ? atoi(argv[8]) : 16;
+  auto w = make_weights(sets, K, N, g, dtype);
+  void *x, *y, *ws;
+  CK(hipMalloc(&x, (size_t)M * K * 2)); fill_scales(x, (size_t)M * K, dtype, -1.f, 1.f);
+  CK(hipMalloc(&y, (size_t)M * N * 2));
+  const size_t ws_bytes = 4096 + (64u << 20);
+  CK(hipMalloc(&ws, ws_bytes)); CK(hipMemset(ws, 0, ws_bytes));
+  hipStream_t st; CK(hipStreamCreate(&st));
+  const int max_wg = 4096;
+  std::vector<unsigned long long> h((size_t)max_wg * 8);
+  const int reps = argc > 9 ? atoi(argv[9]) : 2 * sets + 3;
+  for (int rep = 0; rep < reps; ++rep) {
+    CK(hipMemsetAsync((char*)ws + (48u << 20), 0, (size_t)max_wg * 64, st));
+    int rc = awq_gemm_ex(x, K, w[rep % sets].qw, w[rep % sets].sc, w[rep % sets].qz, nullptr, y, ws, ws_bytes, M, K, N, g, dtype, 1, AWQ_GEMM_SKINNY, tune, st);
+    if (rc) { fprintf(stderr, "awq_gemm_ex: %s\n", awq_hip_status_string(rc)); return 1; }
+    CK(hipStreamSynchronize(st));
+  }
+  CK(hipMemcpy(h.data(), (char*)ws + (48u << 20), (size_t)max_wg * 64, hipMemcpyDeviceToHost));
+  unsigned long long t0 = ~0ull; int nwg = 0;
+  for (int b = 0; b < max_wg; ++b) if (h[(size_t)b * 8]) { nwg = b + 1; if (h[(size_t)b * 8] < t0) t0 = h[(size_t)b * 8]; }
+  const char* names[8] = {"start", "loads issued", "loads landed", "compute done", "after barrier", "partial stored", "ticket drawn", "reduced (last arriver)"};
+  printf("stamps: %d workgroups, times in us after the first workgroup started (100 MHz clock)\n", nwg);
+  {   // slot 2 holds shader-clock ticks from kernel start to the end of the k-loop, slot 3 - slot 0 the same span in 10 ns units
+    std::vector<double> mhz;
+    for (int b = 0; b < nwg; ++b) if (h[(size_t)b * 8 + 2] && h[(size_t)b * 8 + 3] > h[(size_t)b * 8]) mhz.push_back((double)h[(size_t)b * 8 + 2] / ((double)(h[(size_t)b * 8 + 3] - h[(size_t)b * 8]) * 0.01));
+    if (!mhz.empty()) { std::sort(mhz.begin(), mhz.end()); printf("  shader clock during the k-loop: median %.0f MHz (min %.0f, max %.0f)\n", mhz[mhz.size() / 2], mhz.front(), mhz.back()); }
+  }
+  for (int slot = 0; slot < 8; ++slot) {
+    if (slot == 2) continue;
+    std::vector<double> v;
+    for (int b = 0; b < nwg; ++b) if (h[(size_t)b * 8 + slot]) v.push_back((double)(h[(size_t)b * 8 + slot] - t0) * 0.01);
+    if (v.empty()) continue;
+    std::sort(v.begin(), v.end());
+    printf("  %-24s n=%4zu  min %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f\n", names[slot], v.size(), v.front(), v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+  }
+  return 0;
+}
+
 static int cmd_dequant(int argc, char** argv) {
   if (argc < 6) { fprintf(stderr, "usage: kbench dequant K N g dtype [sets] [iters]\n"); return 2; }
   const int K = atoi(argv[2]), N = atoi(argv[3]), g = atoi(argv[4]), dtype = atoi(argv[5]);
@@ -251,6 +321,7 @@ int main(int argc, char** argv) {
   std::string cmd = argv[1];
   if (cmd == "gemm") return cmd_gemm(argc, argv);
   if (cmd == "dequant") return cmd_dequant(argc, argv);
+  if (cmd == "stamps") return cmd_stamps(argc, argv);
   if (cmd == "read") return cmd_read(argc, argv);
   fprintf(stderr, "unknown command %s\n", argv[1]);
   return 2;
