@@ -36,9 +36,10 @@ class TensorParallelGroup:
             return t
         if dim < 0:
             dim += t.dim()
-        parts = torch.empty((self.world_size,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(parts, t.contiguous(), group=self.device_group)
-        parts = parts.movedim(0, dim)               # [..., world, size_dim, ...]
+        t = t.contiguous()
+        flat = torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(flat, t, group=self.device_group)      # rank-major along dim 0
+        parts = flat.view((self.world_size,) + tuple(t.shape)).movedim(0, dim)   # [..., world, size_dim, ...]
         shape = list(t.shape)
         shape[dim] *= self.world_size
         return parts.reshape(shape)

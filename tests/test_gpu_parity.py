@@ -275,7 +275,9 @@ def test_awq_linear_method_apply_matches_oracle(ops):
         want = awq_ref.to_f64(awq_ref.awq_linear_apply(x, qw, s, qz, b), "f16")
         got = awq_ref.to_f64(to_np(y), "f16")
         from tests.util import ulp
-        # fused: one output ulp; dequant + vendor-BLAS matmul is third-party arithmetic (its fp32 sums
-        # are ordered differently), so a rounding-boundary flip before the bias add can cost a second ulp
+        # One ulp of the PRE-bias sum (a rounding-boundary flip of the fp32-accumulated sum against the exact
+        # one) — which can be several ulps of a smaller post-bias result when the bias cancels.  The vendor
+        # BLAS of the dequant_matmul mode is third-party arithmetic: allow it a second flip.
+        pre = awq_ref.to_f64(awq_ref.awq_linear_apply(x, qw, s, qz, None), "f16")
         tol = 1.01 if mode == "fused" else 2.02
-        assert np.all(np.abs(got - want) <= tol * ulp(want, "f16")), mode
+        assert np.all(np.abs(got - want) <= tol * np.maximum(ulp(want, "f16"), ulp(pre, "f16"))), mode
