@@ -135,6 +135,35 @@ def test_gemm_skinny_vs_oracle(ops, dt, M):
         assert_gemm_close(y, exact, dt, what=f"skinny M={M} K={K} N={N} g={g} tune={tune} {dt}")
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_gemm_tiled_vs_oracle(ops, dt):
+    """LDS-tiled MFMA kernel (prefill shapes): ragged M and N against the 128 x 128 tile, several K steps,
+    g = 32 / 64 / 128 / K, more tiles than one XCD round."""
+    for (M, K, N, g) in [(1, 128, 128, 128), (17, 256, 136, 64), (64, 1024, 1056, 128), (100, 512, 128, 32),
+                         (128, 128, 256, 128), (129, 384, 264, 384), (300, 256, 2304, 128), (2048, 128, 128, 128)]:
+        y, exact, _ = _gemm_case(ops, M, K, N, g, dt, "A", seed=M * 31 + K + N, variant=_lib.GEMM_TILED)
+        assert_gemm_close(y, exact, dt, what=f"tiled M={M} K={K} N={N} g={g} {dt}")
+
+
+def test_gemm_tiled_prefill_shape_properties(ops):
+    """BASELINE configs[2] (M = 2048, K = 4096, N = 11008): one-hot rows must reproduce awq_dequantize rows
+    bit for bit, and a random sample of outputs is checked against the exact-sum oracle."""
+    K, N, g, M = 4096, 11008, 128, 2048
+    qw, s, qz = synth.make_awq_weights(K, N, g, "f16", "A", 777)
+    dq, ds, dz = _dev(qw, s, qz)
+    W = ops.awq_dequantize(dq, ds, dz)
+    x = torch.zeros(M, K, dtype=torch.float16, device=DEV)
+    ks = torch.arange(M, device=DEV) * 2 % K
+    x[torch.arange(M, device=DEV), ks] = 1.0
+    y = ops.awq_gemm(x, dq, ds, dz, 1)
+    assert torch.equal(y, W[ks])
+    xr = synth.make_activations(M, K, "f16", "A", 778)
+    y = to_np(ops.awq_gemm(to_torch(xr, DEV), dq, ds, dz, 1))
+    rows = [0, 1, 127, 128, 1000, 2047]
+    _, exact = c_oracle.gemm(xr[rows], qw, s, qz, want_exact=True)
+    assert_gemm_close(y[rows], exact, "f16", what="prefill sample rows")
+
+
 @pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
 def test_gemm_generic_vs_oracle(ops, dt):
     for (M, K, N, g) in [(1, 128, 8, 128), (5, 96, 40, 32), (9, 200, 520, 100), (33, 256, 72, 64), (4, 64, 1024, 64)]:
@@ -280,4 +309,5 @@ def test_awq_linear_method_apply_matches_oracle(ops):
         # BLAS of the dequant_matmul mode is third-party arithmetic: allow it a second flip.
         pre = awq_ref.to_f64(awq_ref.awq_linear_apply(x, qw, s, qz, None), "f16")
         tol = 1.01 if mode == "fused" else 2.02
-        assert np.all(np.abs(got - want) <= tol * np.maximum(ulp(want, "f16"), ulp(pre, "f16"))), mode
+        # ... and the bias add rounds once more, which can move the result by one further ulp of its own
+        assert np.all(np.abs(got - want) <= tol * (ulp(want, "f16") + ulp(pre, "f16"))), mode
