@@ -32,6 +32,10 @@ if ROOT not in sys.path:
 
 K_DIM, N_DIM, GROUP = 4096, 11008, 128
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# HBM bytes per M=1 launch from the PMC counters (separate rocprofv3 --pmc passes of tools/kbench, files
+# profiles/r01_pmc_{fetch,write}_size_gemv_m1.csv): FETCH_SIZE 11,870.5 KiB x 2 (gfx950 reports half of a
+# wide coalesced read stream; calibrated on a 22.5 MB linear read) + WRITE_SIZE 513.75 KiB
+PMC_TRAFFIC_BYTES_M1 = int((2 * 11870.5 + 513.75) * 1024)
 MFMA_PEAK_TFLOPS = 2500.0       # dense fp16/bf16
 
 
@@ -245,7 +249,9 @@ def main():
         bound = "hbm" if M <= 64 else "mfma"
         if bound == "hbm":
             out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                               "frac": round(ach / HBM_PEAK_GBPS, 4),
+                               "traffic": PMC_TRAFFIC_BYTES_M1 if M == 1 else None,
+                               "traffic_note": "bytes per launch, rocprofv3 PMC passes committed under profiles/ (not collected live)",
                                "kernel": "gemm_skinny_kernel", "us_per_launch": round(per_launch * 1e6, 3),
                                "cache_hot_GBps": round(algorithmic_bytes(M) / (hot / launches_per_step) / 1e9, 1) if hot else None}
         else:

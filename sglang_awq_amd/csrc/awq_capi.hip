@@ -90,6 +90,24 @@ int awq_gemm_ex(const void* x, int64_t ldx, const int32_t* qweight, const void* 
     if (!workspace || workspace_bytes < awq_gemm_workspace_bytes(M, K, N, group_size, dtype)) return AWQ_ERR_WORKSPACE;
     return launch_gemm_skinny(a);
   }
+  // 16 < M <= 48: the 128-row tiles of the prefill kernel would leave most CUs idle (N / 128 workgroups);
+  // two or three passes of the decode kernel over 16-row slabs of x are faster (measured 82 us tiled vs
+  // ~20 us per pass at 4096 x 11008).  Passes are stream-ordered, so they can share the workspace.
+  if (M > kSkinnyMaxM && M <= 3 * kSkinnyMaxM) {
+    GemmArgs c = a;
+    c.M = kSkinnyMaxM;
+    if (skinny_supported(c) && workspace && workspace_bytes >= awq_gemm_workspace_bytes(kSkinnyMaxM, K, N, group_size, dtype)) {
+      const size_t eb2 = 2;   // skinny_supported() admitted fp16 / bf16 only
+      for (int64_t m0 = 0; m0 < M; m0 += kSkinnyMaxM) {
+        c.M = (int)(M - m0 < kSkinnyMaxM ? M - m0 : kSkinnyMaxM);
+        c.x = (const char*)x + (size_t)m0 * ldx * eb2;
+        c.y = (char*)y + (size_t)m0 * N * eb2;
+        const int rc2 = launch_gemm_skinny(c);
+        if (rc2) return rc2;
+      }
+      return AWQ_OK;
+    }
+  }
   if (tiled_supported(a)) return launch_gemm_tiled(a);
   return launch_gemm_generic(a);
 }
