@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Llama-2-7B-AWQ decode tok/s, TP=1, batch 1-32 (BASELINE configs[3]) on one MI355X.
+
+Method of the reference's bench_one_batch.py (:497-623): per decode step `synchronize; tic; decode;
+synchronize`, report the MEDIAN step latency and batch / latency as tok/s.  The decode step is this
+package's minimal Llama (sglang_awq_amd/llama.py) with every projection an AWQ linear on the gfx950
+kernels, replayed from one captured HIP graph; weights are synthetic (no checkpoint here; the reference
+benchmarks `--load-format dummy` the same way).  Prints one JSON line per batch size and a final
+summary line; `--cpu-seconds` bounds the CPU baseline (the reference's eager-torch CPU dequantise +
+matmul, timed on ONE decoder layer's four linears and scaled by the layer count).
+
+    python bench_decode.py [--model 7b] [--batches 1,2,4,8,16,32] [--steps 64] [--context 128]
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="7b", choices=["7b", "tiny"])
+    ap.add_argument("--batches", default="1,2,4,8,16,32")
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--context", type=int, default=128, help="KV positions already in the cache when timing starts")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    args = ap.parse_args()
+
+    import torch
+
+    from sglang_awq_amd.awq import AWQConfig
+    from sglang_awq_amd.llama import GraphedDecoder, LlamaConfig, LlamaForCausalLM
+
+    dev = torch.device("cuda", 0)
+    cfg = LlamaConfig.llama2_7b() if args.model == "7b" else LlamaConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=4,
+                                                                          num_attention_heads=8, num_key_value_heads=8, vocab_size=2048)
+    batches = [int(b) for b in args.batches.split(",")]
+    max_seq = args.context + args.steps + 16
+    with torch.device(dev):
+        model = LlamaForCausalLM(cfg, AWQConfig(4, 128, True), max_batch=max(batches), max_seq=max_seq)
+    model.init_synthetic_(0)
+    torch.cuda.synchronize()
+
+    # weight bytes one decode step must stream (packed AWQ linears + fp16 lm_head): the HBM floor
+    lin_bytes = sum(l.qweight.numel() * 4 + l.qzeros.numel() * 4 + l.scales.numel() * 2
+                    for layer in model.layers for l in (layer.qkv_proj, layer.o_proj, layer.gate_up_proj, layer.down_proj))
+    head_bytes = model.lm_head.numel() * 2
+    results = []
+    for B in batches:
+        dec = GraphedDecoder(model, B, start_pos=args.context).capture(warmup=2)
+        dec.run(3)
+        lat = []
+        for _ in range(args.steps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dec.graph.replay()
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+        med = statistics.median(lat)
+        # device-only time of the same step: K replays back to back between HIP events
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dec.pos.fill_(args.context)
+        e0.record()
+        for _ in range(16):
+            dec.graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        dev_ms = e0.elapsed_time(e1) / 16
+        r = {"metric": "Llama-2-7B-AWQ decode tok/s TP=1" if args.model == "7b" else "tiny-llama decode tok/s", "batch": B,
+             "value": round(B / med, 1), "unit": "tok/s", "median_step_ms": round(med * 1e3, 4), "device_step_ms": round(dev_ms, 4),
+             "tok_per_s_device": round(B / (dev_ms * 1e-3), 1), "context": args.context, "steps": args.steps,
+             "weight_GB_per_step": round((lin_bytes + head_bytes) / 1e9, 3),
+             "hbm_GBps_device": round((lin_bytes + head_bytes) / (dev_ms * 1e-3) / 1e9, 1), "data": "synthetic", "dtype": "f16"}
+        results.append(r)
+        print(json.dumps(r), flush=True)
+        del dec
+
+    cpu = None
+    if args.cpu_seconds > 0:
+        from oracle import torch_cpu
+        from sglang_awq_amd import synth
+
+        shapes = [(cfg.hidden_size, 3 * cfg.hidden_size), (cfg.hidden_size, cfg.hidden_size),
+                  (cfg.hidden_size, 2 * cfg.intermediate_size), (cfg.intermediate_size, cfg.hidden_size)]
+        tens = []
+        for i, (K, N) in enumerate(shapes):
+            qw, s, qz = synth.make_awq_weights(K, N, 128, "f16", "A", 50 + i)
+            x = synth.make_activations(1, K, "f16", "A", 60 + i)
+            tens.append(tuple(torch.from_numpy(a.copy()) for a in (x, qw, s, qz)))
+        for x, qw, s, qz in tens:
+            torch_cpu.linear_cpu(x, qw, s, qz)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < args.cpu_seconds:
+            for x, qw, s, qz in tens:
+                torch_cpu.linear_cpu(x, qw, s, qz)
+            n += 1
+        per_layer = (time.perf_counter() - t0) / n
+        cpu = {"value": round(1.0 / (per_layer * cfg.num_hidden_layers), 4), "unit": "tok/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"{n} x the four AWQ linears of ONE decoder layer at batch 1 (eager torch CPU dequantise + matmul), "
+                         f"{per_layer * 1e3:.0f} ms per layer, scaled by {cfg.num_hidden_layers} layers; attention / lm_head not counted"}
+    print(json.dumps({"summary": {f"b{r['batch']}": r["value"] for r in results}, "unit": "tok/s", "cpu_baseline": cpu}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,200 @@
+"""Minimal Llama decode harness around the AWQ linears (BASELINE configs 4-5).
+
+Only the wiring either side of the hot path: the four quantised projections of every layer are this
+package's `QKVParallelLinear` / `RowParallelLinear` / `MergedColumnParallelLinear` with
+`AWQLinearMethod` — exactly the layers `LlamaAttention` / `LlamaMLP` build in the reference
+(python/sglang/srt/models/llama.py:61-200).  Everything else (RMSNorm, neox RoPE, attention over a
+static KV cache, SiLU-and-mul, greedy sampling) is plain PyTorch-ROCm ops: no AITER, no Triton, no
+serving runtime.  The whole decode step is launch-only, so it is captured once into a HIP graph and
+replayed (the reference's decode path replays graphs: model_executor/model_runner.py:2765-2771).
+
+Weights are synthetic (random packed int4, realistic scales): there is no checkpoint in this
+environment; the reference measures dummy-weight decode the same way (`--load-format dummy`,
+weight_utils.py:1108-1137).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from .awq import AWQConfig
+from .distributed import get_tensor_model_parallel_world_size
+from .linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
+
+
+@dataclass
+class LlamaConfig:
+    hidden_size: int = 4096
+    intermediate_size: int = 11008
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 32
+    vocab_size: int = 32000
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    max_position_embeddings: int = 4096
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+    @staticmethod
+    def llama2_7b() -> "LlamaConfig":
+        return LlamaConfig()
+
+    @staticmethod
+    def llama2_70b() -> "LlamaConfig":
+        return LlamaConfig(hidden_size=8192, intermediate_size=28672, num_hidden_layers=80, num_attention_heads=64,
+                           num_key_value_heads=8)
+
+
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    xf = x.float()
+    return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype) * weight
+
+
+def apply_rope_neox(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """x [B, H, D]; cos / sin [B, 1, D/2] (rotate-half convention, as get_rope(..., is_neox_style=True))."""
+    d = x.shape[-1] // 2
+    x1, x2 = x[..., :d].float(), x[..., d:].float()
+    return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], dim=-1).to(x.dtype)
+
+
+class LlamaDecoderLayer(torch.nn.Module):
+    def __init__(self, cfg: LlamaConfig, quant: AWQConfig, layer_id: int, max_batch: int, max_seq: int, dtype: torch.dtype):
+        super().__init__()
+        tp = get_tensor_model_parallel_world_size()
+        self.cfg = cfg
+        self.num_heads = cfg.num_attention_heads // tp
+        self.num_kv_heads = max(1, cfg.num_key_value_heads // tp)
+        self.head_dim = cfg.head_dim
+        self.q_size = self.num_heads * self.head_dim
+        self.kv_size = self.num_kv_heads * self.head_dim
+        p = f"model.layers.{layer_id}"
+        self.qkv_proj = QKVParallelLinear(cfg.hidden_size, self.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads,
+                                          bias=False, quant_config=quant, params_dtype=dtype, prefix=f"{p}.self_attn.qkv_proj")
+        self.o_proj = RowParallelLinear(cfg.num_attention_heads * self.head_dim, cfg.hidden_size, bias=False,
+                                        quant_config=quant, params_dtype=dtype, prefix=f"{p}.self_attn.o_proj")
+        self.gate_up_proj = MergedColumnParallelLinear(cfg.hidden_size, [cfg.intermediate_size] * 2, bias=False,
+                                                       quant_config=quant, params_dtype=dtype, prefix=f"{p}.mlp.gate_up_proj")
+        self.down_proj = RowParallelLinear(cfg.intermediate_size, cfg.hidden_size, bias=False, quant_config=quant,
+                                           params_dtype=dtype, prefix=f"{p}.mlp.down_proj")
+        self.input_layernorm = torch.nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype), requires_grad=False)
+        self.post_attention_layernorm = torch.nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype), requires_grad=False)
+        # static KV cache [B, H_kv, S, D]: fixed shapes keep the step graph-capturable
+        self.register_buffer("k_cache", torch.zeros(max_batch, self.num_kv_heads, max_seq, self.head_dim, dtype=dtype), persistent=False)
+        self.register_buffer("v_cache", torch.zeros(max_batch, self.num_kv_heads, max_seq, self.head_dim, dtype=dtype), persistent=False)
+
+    def forward(self, h: torch.Tensor, pos: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        B = h.shape[0]
+        x = rms_norm(h, self.input_layernorm, self.cfg.rms_norm_eps)
+        qkv, _ = self.qkv_proj(x)
+        q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+        q = apply_rope_neox(q.view(B, self.num_heads, self.head_dim), cos, sin)
+        k = apply_rope_neox(k.view(B, self.num_kv_heads, self.head_dim), cos, sin)
+        v = v.view(B, self.num_kv_heads, self.head_dim)
+        idx = pos.view(B, 1, 1, 1).expand(B, self.num_kv_heads, 1, self.head_dim)
+        self.k_cache[:B].scatter_(2, idx, k.unsqueeze(2))
+        self.v_cache[:B].scatter_(2, idx, v.unsqueeze(2))
+        attn = F.scaled_dot_product_attention(q.unsqueeze(2), self.k_cache[:B], self.v_cache[:B], attn_mask=mask,
+                                              enable_gqa=self.num_heads != self.num_kv_heads)
+        o, _ = self.o_proj(attn.reshape(B, self.q_size))
+        h = h + o
+        x = rms_norm(h, self.post_attention_layernorm, self.cfg.rms_norm_eps)
+        gu, _ = self.gate_up_proj(x)
+        half = gu.shape[-1] // 2
+        act = F.silu(gu[:, :half]) * gu[:, half:]
+        d, _ = self.down_proj(act)
+        return h + d
+
+
+class LlamaForCausalLM(torch.nn.Module):
+    """Decode-only Llama with AWQ projections, fp16 embedding / lm_head (as AutoAWQ checkpoints keep them)."""
+
+    def __init__(self, cfg: LlamaConfig, quant: AWQConfig, max_batch: int = 32, max_seq: int = 512, dtype: torch.dtype = torch.float16):
+        super().__init__()
+        self.cfg, self.max_batch, self.max_seq, self.dtype = cfg, max_batch, max_seq, dtype
+        self.embed_tokens = torch.nn.Parameter(torch.zeros(cfg.vocab_size, cfg.hidden_size, dtype=dtype), requires_grad=False)
+        self.layers = torch.nn.ModuleList(LlamaDecoderLayer(cfg, quant, i, max_batch, max_seq, dtype) for i in range(cfg.num_hidden_layers))
+        self.norm = torch.nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype), requires_grad=False)
+        self.lm_head = torch.nn.Parameter(torch.zeros(cfg.vocab_size, cfg.hidden_size, dtype=dtype), requires_grad=False)
+        inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, cfg.head_dim, 2, dtype=torch.float32) / cfg.head_dim))
+        t = torch.arange(max_seq, dtype=torch.float32)
+        freqs = torch.outer(t, inv)
+        self.register_buffer("cos_table", freqs.cos(), persistent=False)
+        self.register_buffer("sin_table", freqs.sin(), persistent=False)
+        self.register_buffer("arange_seq", torch.arange(max_seq), persistent=False)
+
+    @torch.no_grad()
+    def init_synthetic_(self, seed: int = 0):
+        """Random packed int4 weights, scales 0.005..0.02 / sqrt-ish fan-in scaling so activations stay O(1)."""
+        g = torch.Generator(device=self.embed_tokens.device)
+        g.manual_seed(seed)
+        dev = self.embed_tokens.device
+        self.embed_tokens.copy_((torch.randn(self.embed_tokens.shape, device=dev, generator=g) * 0.5).to(self.dtype))
+        self.lm_head.copy_((torch.randn(self.lm_head.shape, device=dev, generator=g) * 0.02).to(self.dtype))
+        for layer in self.layers:
+            for lin in (layer.qkv_proj, layer.o_proj, layer.gate_up_proj, layer.down_proj):
+                K = lin.qweight.shape[0]
+                lin.qweight.copy_(torch.randint(-2 ** 31, 2 ** 31 - 1, lin.qweight.shape, dtype=torch.int64, device=dev, generator=g).to(torch.int32))
+                lin.qzeros.copy_(torch.randint(-2 ** 31, 2 ** 31 - 1, lin.qzeros.shape, dtype=torch.int64, device=dev, generator=g).to(torch.int32))
+                s = (0.5 + torch.rand(lin.scales.shape, device=dev, generator=g)) * (0.15 / (K ** 0.5))   # W std ~ 1/sqrt(K)
+                lin.scales.copy_(s.to(self.dtype))
+                lin.process_weights_after_loading()
+        return self
+
+    def step(self, tokens: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+        """One decode step.  tokens [B] int64, pos [B] int64 (position of these tokens) -> next tokens [B]."""
+        return self.logits(tokens, pos).argmax(-1)
+
+    def logits(self, tokens: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+        h = self.embed_tokens[tokens]
+        cos = self.cos_table[pos].unsqueeze(1)
+        sin = self.sin_table[pos].unsqueeze(1)
+        mask = (self.arange_seq.view(1, 1, 1, -1) <= pos.view(-1, 1, 1, 1))          # attend to cache slots <= pos
+        for layer in self.layers:
+            h = layer(h, pos, cos, sin, mask)
+        h = rms_norm(h, self.norm, self.cfg.rms_norm_eps)
+        return torch.matmul(h, self.lm_head.t())
+
+
+class GraphedDecoder:
+    """Captures `model.step` for a fixed batch size into one HIP graph; `run(n)` replays n decode steps with the
+    token / position buffers advanced on device between replays (no host round trip inside the timed loop)."""
+
+    def __init__(self, model: LlamaForCausalLM, batch: int, start_pos: int = 0):
+        self.model, self.batch = model, batch
+        dev = model.embed_tokens.device
+        self.tokens = torch.zeros(batch, dtype=torch.int64, device=dev)
+        self.pos = torch.full((batch,), start_pos, dtype=torch.int64, device=dev)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+
+    def _step(self):
+        nxt = self.model.step(self.tokens, self.pos)
+        self.tokens.copy_(nxt)
+        self.pos.add_(1)
+
+    @torch.no_grad()
+    def capture(self, warmup: int = 2):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._step()
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._step()
+        return self
+
+    @torch.no_grad()
+    def run(self, steps: int) -> List[int]:
+        for _ in range(steps):
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._step()
+        return self.tokens.tolist()
