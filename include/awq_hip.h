@@ -104,6 +104,25 @@ int awq_gemm_ex(const void* x, int64_t ldx, const int32_t* qweight, const void* 
                 int64_t M, int64_t K, int64_t N, int64_t group_size, int dtype, int split_k_iters,
                 int variant, int64_t tune, void* stream);
 
+/*
+ * Optional one-time re-layout for decode.  The reference re-lays AWQ weights out only for
+ * its NVIDIA Marlin path (sgl-kernel/csrc/gemm/marlin/awq_marlin_repack.cu:13-253, called from
+ * AWQMarlinLinearMethod.process_weights_after_loading); its plain AWQ method keeps the checkpoint layout
+ * (awq.py:429-432).  awq_repack writes an MFMA-fragment-major copy of (qweight, qzeros, scales) into
+ * `packed` (awq_repacked_bytes() bytes, 16-byte aligned); awq_gemm_repacked then computes the same result as
+ * awq_gemm for M <= 16 — same per-element rounding, fp32 accumulation, bias epilogue — from that copy, with
+ * linear weight streaming and no cross-workgroup reduction (no workspace).
+ * Supported: fp16, K % 128 == 0, group_size % 128 == 0; otherwise awq_repacked_bytes returns 0 and the other
+ * two return AWQ_ERR_BAD_VARIANT (callers keep using awq_gemm).
+ */
+size_t awq_repacked_bytes(int64_t K, int64_t N, int64_t group_size, int dtype);
+
+int awq_repack(const int32_t* qweight, const void* scales, const int32_t* qzeros, void* packed, int64_t K,
+               int64_t N, int64_t group_size, int dtype, void* stream);
+
+int awq_gemm_repacked(const void* x, int64_t ldx, const void* packed, const void* bias, void* y, int64_t M,
+                      int64_t K, int64_t N, int64_t group_size, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,9 @@ EXPORTS = (
     "awq_gemm_workspace_bytes",
     "awq_gemm",
     "awq_gemm_ex",
+    "awq_repacked_bytes",
+    "awq_repack",
+    "awq_gemm_repacked",
 )
 ABI_VERSION = 1
 
@@ -64,6 +67,12 @@ def _bind(L):
     L.awq_gemm.restype = ci
     L.awq_gemm_ex.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, sz, i64, i64, i64, i64, ci, ci, ci, i64, vp]
     L.awq_gemm_ex.restype = ci
+    L.awq_repacked_bytes.argtypes = [i64, i64, i64, ci]
+    L.awq_repacked_bytes.restype = sz
+    L.awq_repack.argtypes = [vp, vp, vp, vp, i64, i64, i64, ci, vp]
+    L.awq_repack.restype = ci
+    L.awq_gemm_repacked.argtypes = [vp, i64, vp, vp, vp, i64, i64, i64, i64, ci, vp]
+    L.awq_gemm_repacked.restype = ci
 
 
 def load():

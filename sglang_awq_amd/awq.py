@@ -86,8 +86,14 @@ class AWQConfig(QuantizationConfig):
 class AWQLinearMethod(LinearMethodBase):
     """Linear method for AWQ (awq.py:352-451)."""
 
-    def __init__(self, quant_config: AWQConfig, apply_mode: Optional[str] = None):
+    # decode batches at or below this go to the repacked-layout kernel when a repacked copy exists
+    REPACKED_MAX_M = 16
+
+    def __init__(self, quant_config: AWQConfig, apply_mode: Optional[str] = None, repack: Optional[bool] = None):
         self.quant_config = quant_config
+        if repack is None:
+            repack = os.environ.get("SGLANG_AWQ_AMD_REPACK", "1") != "0"
+        self.repack = repack
         mode = apply_mode or os.environ.get("SGLANG_AWQ_AMD_APPLY", "fused")
         if mode not in ("fused", "dequant_matmul"):
             raise ValueError(f"apply_mode must be 'fused' or 'dequant_matmul', got {mode!r}")
@@ -127,6 +133,14 @@ class AWQLinearMethod(LinearMethodBase):
         layer.qweight = torch.nn.Parameter(layer.qweight.data, requires_grad=False)
         layer.qzeros = torch.nn.Parameter(layer.qzeros.data, requires_grad=False)
         layer.scales = torch.nn.Parameter(layer.scales.data, requires_grad=False)
+        # Optional one-time MFMA-fragment-major copy for decode (the CDNA4 analogue of the reference's
+        # awq_marlin_repack step, awq.py AWQMarlinLinearMethod.process_weights_after_loading).  The original
+        # tensors stay: awq_dequantize and the prefill kernel consume the checkpoint layout.
+        layer.awq_packed = None
+        if self.repack and self.apply_mode == "fused" and layer.qweight.is_cuda and layer.scales.dtype == torch.float16:
+            from . import ops
+
+            layer.awq_packed = ops.awq_repack(layer.qweight.data, layer.scales.data, layer.qzeros.data)
 
     def apply(self, layer: torch.nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         from . import ops
@@ -134,7 +148,11 @@ class AWQLinearMethod(LinearMethodBase):
         qweight, scales, qzeros = layer.qweight, layer.scales, layer.qzeros
         out_shape = x.shape[:-1] + (qweight.shape[-1] * self.quant_config.pack_factor,)
         reshaped_x = x.reshape(-1, x.shape[-1])
-        if self.apply_mode == "fused":
+        packed = getattr(layer, "awq_packed", None)
+        if packed is not None and reshaped_x.shape[0] <= self.REPACKED_MAX_M and reshaped_x.shape[0] > 0:
+            K = qweight.shape[0]
+            out = ops.awq_gemm_repacked(reshaped_x, packed, K, out_shape[-1], K // scales.shape[0], bias)
+        elif self.apply_mode == "fused":
             out = ops.awq_linear(reshaped_x, qweight, scales, qzeros, bias)
         else:
             out = torch.matmul(reshaped_x, ops.awq_dequantize(qweight, scales, qzeros))

@@ -119,4 +119,32 @@ int awq_gemm(const void* x, int64_t ldx, const int32_t* qweight, const void* sca
                      split_k_iters, AWQ_GEMM_AUTO, 0, stream);
 }
 
+size_t awq_repacked_bytes(int64_t K, int64_t N, int64_t group_size, int dtype) {
+  return repacked_supported(K, N, group_size, dtype) ? repacked_bytes(K, N, group_size) : 0;
+}
+
+int awq_repack(const int32_t* qweight, const void* scales, const int32_t* qzeros, void* packed, int64_t K, int64_t N,
+               int64_t group_size, int dtype, void* stream) {
+  int rc = check_common(qweight, scales, qzeros, K, N, group_size, dtype);
+  if (rc) return rc;
+  if (!packed) return AWQ_ERR_NULL_POINTER;
+  if (((uintptr_t)packed) & 15) return AWQ_ERR_MISALIGNED;
+  return launch_repack(qweight, scales, qzeros, packed, K, N, group_size, dtype, (hipStream_t)stream);
+}
+
+int awq_gemm_repacked(const void* x, int64_t ldx, const void* packed, const void* bias, void* y, int64_t M, int64_t K,
+                      int64_t N, int64_t group_size, int dtype, void* stream) {
+  if (!packed) return AWQ_ERR_NULL_POINTER;
+  if (K <= 0 || N <= 0 || group_size <= 0 || N % 8 || K % group_size || M < 0 || ldx < K) return AWQ_ERR_BAD_SHAPE;
+  if (M == 0) return AWQ_OK;
+  if (!x || !y) return AWQ_ERR_NULL_POINTER;
+  if ((((uintptr_t)packed) & 15) || (((uintptr_t)y) & 1)) return AWQ_ERR_MISALIGNED;
+  GemmArgs a;
+  a.x = x; a.ldx = ldx; a.qweight = nullptr; a.scales = nullptr; a.qzeros = nullptr; a.bias = bias; a.y = y;
+  a.workspace = nullptr; a.workspace_bytes = 0;
+  a.M = (int)M; a.K = (int)K; a.N = (int)N; a.g = (int)group_size; a.dtype = dtype; a.tune = 0;
+  a.stream = (hipStream_t)stream;
+  return launch_gemv_repacked(a, packed);
+}
+
 }  // extern "C"

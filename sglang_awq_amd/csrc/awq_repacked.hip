@@ -1,0 +1,274 @@
+// MFMA-fragment-major re-layout of AWQ weights + the decode GEMV that consumes it (gfx950).
+//
+// The reference keeps the AutoAWQ layout at load time (process_weights_after_loading is a no-op
+// re-wrap, awq.py:429-432) and has a one-time re-layout only for its NVIDIA Marlin path
+// (sgl-kernel/csrc/gemm/marlin/awq_marlin_repack.cu:13-253).  This is the CDNA4
+// counterpart: an optional, one-time repack into the layout v_mfma_f32_16x16x32_f16 wants, so the
+// decode kernel streams the weights linearly, needs no in-register transposes, no split-K across
+// workgroups and 12 accumulator registers instead of 128.  The original-layout ops stay the
+// drop-in boundary; numerics are identical (every W element is still (q - z) * s rounded once to
+// fp16, products exact, fp32 accumulation, one final rounding).
+//
+// Layout (all little-endian dwords), NG = ceil(N / 16) column groups, KB = K / 128 k-blocks:
+//   qw_r[NG][KB][64 lanes][4]   lane l = (q = l >> 4, r = l & 15), dword d: the 8 int4 of column
+//                               n = 16 cg + r for rows k = 128 kb + 32 d + 8 q + j, j = 0..7; row j = 2t sits in
+//                               nibble t, row j = 2t + 1 in nibble t + 4, so (w >> 4t) & 0x000f000f is the packed
+//                               pair (k_2t, k_2t+1): the B fragment of one MFMA comes out of ONE dword in order.
+//                               One wave-wide global_load_dwordx4 = 1 KiB = 128 rows x 16 columns, contiguous.
+//   zs_r[NG][K / g][16]         per (column, quantisation group): low half = scale (fp16 bits), high half =
+//                               fp16(1024 + zero).  Columns >= N are padded with scale 0.
+// A workgroup owns G consecutive column groups (a strip of 16 G columns) for ALL of K; its 8 waves take
+// consecutive k-block ranges and are summed in fixed order through LDS; y is written directly.
+#include "awq_device.h"
+#include "awq_kernels.h"
+
+namespace awq {
+
+constexpr int kRpWaves = 8;
+constexpr int kRpMaxG = 8;
+
+// ------------------------------------------------------------------------------------------ repack
+__global__ __launch_bounds__(256) void repack_qweight_kernel(const uint32_t* __restrict__ qw, uint32_t* __restrict__ out,
+                                                             int K, int C, int NG) {
+  const size_t total = (size_t)NG * (K / 128) * 256;          // dwords
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(idx & 3);
+    const int lane = (int)((idx >> 2) & 63);
+    const size_t blk = idx >> 8;
+    const int kb = (int)(blk % (K / 128));
+    const int cg = (int)(blk / (K / 128));
+    const int q = lane >> 4, r = lane & 15;
+    const int n = cg * 16 + r;
+    uint32_t w = 0;
+    if (n < C * 8) {
+      const int word = n >> 3, jn = n & 7;
+      const int shift = ((jn & 1) << 4) + ((jn >> 1) << 2);    // 4 * {0,4,1,5,2,6,3,7}[jn]
+      const int k0 = kb * 128 + d * 32 + q * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t nib = (qw[(size_t)(k0 + j) * C + word] >> shift) & 0xFu;
+        w |= nib << (((j & 1) << 4) + ((j >> 1) << 2));       // row j: nibble j/2 (even j) or j/2 + 4 (odd j)
+      }
+    }
+    out[idx] = w;
+  }
+}
+
+__global__ __launch_bounds__(256) void repack_zs_kernel(const uint32_t* __restrict__ qz, const uint16_t* __restrict__ scales,
+                                                        uint32_t* __restrict__ out, int groups, int C, int NG) {
+  const size_t total = (size_t)NG * groups * 16;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(idx & 15);
+    const int grp = (int)((idx >> 4) % groups);
+    const int cg = (int)((idx >> 4) / groups);
+    const int n = cg * 16 + r;
+    uint32_t v = 0x64000000u;                                  // zero point 0, scale 0
+    if (n < C * 8) {
+      const int z = nibble_of_col(qz[(size_t)grp * C + (n >> 3)], n & 7);
+      v = ((0x6400u | (uint32_t)z) << 16) | scales[(size_t)grp * C * 8 + n];
+    }
+    out[idx] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ GEMV
+// 8 weights of one column (one dword) -> the 4 packed k-pairs of an MFMA B fragment
+__device__ __forceinline__ u32x4_t rp_dequant(uint32_t w, half2_t z1024, half2_t z64, half2_t s2) {
+  const half2_t sixteenth = {(half_t)0.0625f, (half_t)0.0625f};
+  const uint32_t magic = kMagicF16;
+  const uint32_t w8 = w >> 8;
+  const half2_t d0 = as_h2(and_or(w, kLoNib, magic)) - z1024;
+  const half2_t d1 = __builtin_elementwise_fma(as_h2(and_or(w, kHiNib, magic)), sixteenth, -z64);
+  const half2_t d2 = as_h2(and_or(w8, kLoNib, magic)) - z1024;
+  const half2_t d3 = __builtin_elementwise_fma(as_h2(and_or(w8, kHiNib, magic)), sixteenth, -z64);
+  return (u32x4_t){as_u32(d0 * s2), as_u32(d1 * s2), as_u32(d2 * s2), as_u32(d3 * s2)};
+}
+
+struct RpBlock {            // one k-block (128 rows) of a strip, in registers
+  u32x4_t w[kRpMaxG];       // per column group: 4 dwords = 4 k-steps
+  uint32_t zs[kRpMaxG];     // per column group: (1024 + z | s) of this lane's column
+  u32x4_t xa[4];            // x fragments of the 4 k-steps
+};
+
+template <int G>
+__device__ __forceinline__ void rp_load(RpBlock& b, const u32x4_t* __restrict__ qw_r, const uint32_t* __restrict__ zs_r,
+                                        const uint16_t* __restrict__ x, int64_t ldx, int cg0, int KB, int groups, int g, int kb,
+                                        int lane, int xr) {
+  const int q = lane >> 4, r = lane & 15;
+#pragma unroll
+  for (int c = 0; c < G; ++c) b.w[c] = qw_r[((size_t)(cg0 + c) * KB + kb) * 64 + lane];
+  const int grp = (kb * 128) / g;                      // g >= 128 here (smaller groups take the per-k-step path below)
+#pragma unroll
+  for (int c = 0; c < G; ++c) b.zs[c] = zs_r[((size_t)(cg0 + c) * groups + grp) * 16 + r];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) b.xa[d] = *(const u32x4_t*)(x + (size_t)xr * ldx + kb * 128 + d * 32 + q * 8);
+}
+
+template <int G>
+__device__ __forceinline__ void rp_compute(const RpBlock& b, float4_t (&acc)[kRpMaxG]) {
+  const half2_t c960 = {(half_t)960.f, (half_t)960.f};
+#pragma unroll
+  for (int c = 0; c < G; ++c) {
+    const half2_t s2 = as_h2(pack_lo16(b.zs[c], b.zs[c]));
+    const half2_t z1024 = as_h2(pack_hi16(b.zs[c], b.zs[c]));
+    const half2_t z64 = z1024 - c960;                  // exact: (1024 + z) - 960
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const u32x4_t frag = rp_dequant(b.w[c][d], z1024, z64, s2);
+      acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, b.xa[d]), __builtin_bit_cast(half8_t, frag), acc[c], 0, 0, 0);
+    }
+  }
+}
+
+// T = k-blocks per wave when it is small enough to issue every load up front (straight-line code, exact
+// counted waits); T == 0: any count, double-buffered loop.
+template <int G, int T>
+__global__ __launch_bounds__(kRpWaves * 64, 2) void gemv_repacked_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+                                                                          const u32x4_t* __restrict__ qw_r,
+                                                                          const uint32_t* __restrict__ zs_r,
+                                                                          const void* __restrict__ bias, void* __restrict__ y,
+                                                                          int M, int K, int N, int g, int NG, int per_wave) {
+  extern __shared__ __attribute__((aligned(16))) float red[];    // [kRpWaves][M][16 G]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, r = lane & 15;
+  const int KB = K / 128, groups = K / g;
+  int cg0 = blockIdx.x * G;
+  if (cg0 + G > NG) cg0 = NG - G;                      // last strip overlaps its neighbour (same values written twice)
+  const int xr = r < M ? r : M - 1;
+
+  float4_t acc[kRpMaxG];
+#pragma unroll
+  for (int c = 0; c < G; ++c) acc[c] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int kb_begin = wave * per_wave;
+  int kb_end = kb_begin + per_wave;
+  if (kb_end > KB) kb_end = KB;
+
+  if constexpr (T > 0) {
+    RpBlock buf[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int kb = kb_begin + t < KB ? kb_begin + t : KB - 1;         // clamped: re-read, then weighted by x = 0
+      rp_load<G>(buf[t], qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (kb_begin + t >= KB) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) buf[t].xa[d] = (u32x4_t){0u, 0u, 0u, 0u};
+      }
+      rp_compute<G>(buf[t], acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    // steady state has no branch between a load and its use (exact counted waits); only the prologue and the
+    // <= 3-block tail are conditional
+    RpBlock A, B;
+    int kb = kb_begin;
+    if (kb < kb_end) rp_load<G>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
+    if (kb + 1 < kb_end) rp_load<G>(B, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 1, lane, xr);
+    while (kb + 3 < kb_end) {
+      rp_compute<G>(A, acc);
+      rp_load<G>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 2, lane, xr);
+      rp_compute<G>(B, acc);
+      rp_load<G>(B, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 3, lane, xr);
+      kb += 2;
+    }
+    if (kb < kb_end) rp_compute<G>(A, acc);
+    if (kb + 2 < kb_end) rp_load<G>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 2, lane, xr);
+    if (kb + 1 < kb_end) rp_compute<G>(B, acc);
+    if (kb + 2 < kb_end) rp_compute<G>(A, acc);
+  }
+
+  // D[m = 4q + i][n = r] per column group -> LDS, summed over the 8 waves in fixed order
+  const int SW = 16 * G;
+#pragma unroll
+  for (int c = 0; c < G; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = 4 * q + i;
+      if (m < M) red[((size_t)wave * M + m) * SW + c * 16 + r] = acc[c][i];
+    }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < M * SW; idx += kRpWaves * 64) {
+    const int m = idx / SW, col = idx - m * SW;
+    const int n = cg0 * 16 + col;
+    if (n >= N) continue;
+    float v = red[(size_t)m * SW + col];
+#pragma unroll
+    for (int w = 1; w < kRpWaves; ++w) v += red[((size_t)w * M + m) * SW + col];
+    store_output<AWQ_DTYPE_F16>(y, (size_t)m * N + n, v, bias, n);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host
+static inline int rp_groups(int N) { return (N + 15) / 16; }
+
+size_t repacked_bytes(int64_t K, int64_t N, int64_t g) {
+  if (K <= 0 || N <= 0 || g <= 0 || K % 128 || K % g) return 0;
+  const size_t NG = (size_t)rp_groups((int)N);
+  return NG * (size_t)(K / 128) * 1024 + NG * (size_t)(K / g) * 64;
+}
+
+bool repacked_supported(int64_t K, int64_t N, int64_t g, int dtype) {
+  return dtype == AWQ_DTYPE_F16 && K % 128 == 0 && g % 128 == 0 && K % g == 0 && N % 8 == 0 && K > 0 && N > 0 &&
+         rp_groups((int)N) >= 1;
+}
+
+int launch_repack(const int32_t* qweight, const void* scales, const int32_t* qzeros, void* packed, int64_t K, int64_t N, int64_t g,
+                  int dtype, hipStream_t stream) {
+  if (!repacked_supported(K, N, g, dtype)) return AWQ_ERR_BAD_VARIANT;
+  const int NG = rp_groups((int)N), C = (int)(N / 8);
+  uint32_t* qw_r = (uint32_t*)packed;
+  uint32_t* zs_r = qw_r + (size_t)NG * (K / 128) * 256;
+  hipLaunchKernelGGL(repack_qweight_kernel, dim3(2048), dim3(256), 0, stream, (const uint32_t*)qweight, qw_r, (int)K, C, NG);
+  hipLaunchKernelGGL(repack_zs_kernel, dim3(256), dim3(256), 0, stream, (const uint32_t*)qzeros, (const uint16_t*)scales, zs_r,
+                     (int)(K / g), C, NG);
+  return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
+
+template <int G>
+static void rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wave, int nwg, size_t lds) {
+  const u32x4_t* qw_r = (const u32x4_t*)packed;
+  const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
+  dim3 grid(nwg), block(kRpWaves * 64);
+#define RP_GO(TT)                                                                                                           \
+  hipLaunchKernelGGL((gemv_repacked_kernel<G, TT>), grid, block, lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r, a.bias, \
+                     a.y, a.M, a.K, a.N, a.g, NG, per_wave)
+  switch (per_wave) {
+    case 1: RP_GO(1); break;
+    case 2: RP_GO(2); break;
+    case 3: RP_GO(3); break;
+    case 4: RP_GO(4); break;
+    default: RP_GO(0); break;
+  }
+#undef RP_GO
+}
+
+int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
+  if (!repacked_supported(a.K, a.N, a.g, a.dtype) || a.M < 1 || a.M > 16 || a.ldx % 8 || (((uintptr_t)a.x) & 15)) return AWQ_ERR_BAD_VARIANT;
+  const int NG = rp_groups(a.N);
+  int G = (NG + 255) / 256;                            // one strip per CU
+  if (G > kRpMaxG) G = kRpMaxG;
+  if (G > NG) G = NG;
+  const int nwg = (NG + G - 1) / G;
+  const int KB = a.K / 128;
+  const int per_wave = (KB + kRpWaves - 1) / kRpWaves;
+  const size_t lds = (size_t)kRpWaves * a.M * 16 * G * sizeof(float);
+  if (lds > 64 * 1024) return AWQ_ERR_BAD_VARIANT;
+  switch (G) {
+    case 1: rp_launch<1>(a, packed, NG, per_wave, nwg, lds); break;
+    case 2: rp_launch<2>(a, packed, NG, per_wave, nwg, lds); break;
+    case 3: rp_launch<3>(a, packed, NG, per_wave, nwg, lds); break;
+    case 4: rp_launch<4>(a, packed, NG, per_wave, nwg, lds); break;
+    case 5: rp_launch<5>(a, packed, NG, per_wave, nwg, lds); break;
+    case 6: rp_launch<6>(a, packed, NG, per_wave, nwg, lds); break;
+    case 7: rp_launch<7>(a, packed, NG, per_wave, nwg, lds); break;
+    default: rp_launch<8>(a, packed, NG, per_wave, nwg, lds); break;
+  }
+  return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
+
+}  // namespace awq

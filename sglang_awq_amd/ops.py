@@ -205,6 +205,45 @@ def awq_linear(input, qweight, scales, qzeros, bias=None) -> torch.Tensor:
     return torch.ops.sglang_awq_amd.awq_linear.default(input, qweight, scales, qzeros, bias)
 
 
+def awq_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor) -> Optional[torch.Tensor]:
+    """One-time MFMA-fragment-major copy of an AWQ weight for the decode kernel (include/awq_hip.h awq_repack).
+    Returns a uint8 tensor, or None when the shape / dtype is not supported (callers keep the plain ops)."""
+    K, N, g = _check_awq_tensors(qweight, scales, qzeros)
+    lib = _lib.load()
+    code = _DTYPE_CODE[scales.dtype]
+    nbytes = lib.awq_repacked_bytes(K, N, g, code)
+    if nbytes == 0:
+        return None
+    dev = qweight.device
+    with _on_device(dev):
+        packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        rc = lib.awq_repack(_vp(qweight), _vp(scales), _vp(qzeros), _vp(packed), K, N, g, code,
+                            ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    _lib.check(rc, "awq_repack")
+    return packed
+
+
+def awq_gemm_repacked(input: torch.Tensor, packed: torch.Tensor, K: int, N: int, group_size: int,
+                      bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = input @ W (+ bias) from the repacked copy; M <= 16, fp16.  Same numerics as awq_gemm / awq_linear."""
+    if input.dim() != 2 or input.shape[1] != K or input.dtype != torch.float16:
+        raise RuntimeError(f"awq_gemm_repacked: input must be fp16 [M, {K}], got {input.dtype} {tuple(input.shape)}")
+    if input.stride(1) != 1:
+        input = input.contiguous()
+    if bias is not None and (bias.dtype != torch.float16 or bias.shape != (N,) or not bias.is_contiguous()):
+        raise RuntimeError(f"awq_gemm_repacked: bias must be a contiguous fp16 [{N}] tensor")
+    M = input.shape[0]
+    ldx = input.stride(0) if M > 1 else max(input.stride(0), K)
+    lib = _lib.load()
+    dev = input.device
+    with _on_device(dev):
+        y = torch.empty((M, N), dtype=torch.float16, device=dev)
+        rc = lib.awq_gemm_repacked(_vp(input), ldx, _vp(packed), _vp(bias), _vp(y), M, K, N, group_size, _lib.DTYPE_F16,
+                                   ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    _lib.check(rc, "awq_gemm_repacked")
+    return y
+
+
 def awq_gemm_variant(input, qweight, scales, qzeros, variant: int, tune: int = 0, bias=None) -> torch.Tensor:
     """Force a kernel variant (tests / A-B benchmarks); see include/awq_hip.h awq_gemm_ex."""
     return _gemm_impl(input, qweight, scales, qzeros, bias, 1, variant, tune)

@@ -136,6 +136,53 @@ def test_gemm_skinny_vs_oracle(ops, dt, M):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("M", [1, 3, 8, 16])
+def test_gemm_skinny_loader_consumer_vs_oracle(ops, dt, M):
+    """Loader / consumer (LDS-DMA ring) form of the decode kernel, tune bit 20: few and many k-steps per
+    workgroup (S = 1 at K = 4096 puts 128 k-steps through the 12-slot ring: slot reuse), ragged last column
+    tile, every group size."""
+    DMA = 1 << 20
+    for (K, N, g, S) in [(256, 512, 128, 0), (512, 1056, 128, 1), (1024, 96, 64, 3), (384, 544, 32, 0),
+                         (4096, 1024, 128, 1), (4096, 512, 4096, 2), (2048, 1536, 128, 0), (1056 * 2, 1024, 32, 5)]:
+        y, exact, _ = _gemm_case(ops, M, K, N, g, dt, "A", seed=M * 77 + K + N, variant=_lib.GEMM_SKINNY, tune=DMA | (S << 8))
+        assert_gemm_close(y, exact, dt, what=f"dma M={M} K={K} N={N} g={g} S={S} {dt}")
+
+
+@pytest.mark.parametrize("M", [1, 2, 5, 8, 16])
+def test_gemm_repacked_vs_oracle(ops, M):
+    """MFMA-fragment-major re-layout + its decode kernel: column counts that are not a multiple
+    of 16 (padded group), strips of 1..8 column groups, 1..4 k-blocks per wave (straight-line) and more (loop),
+    g = 128 and g = K."""
+    for (K, N, g) in [(128, 16, 128), (256, 72, 128), (512, 1056, 128), (1024, 4096, 128), (4096, 512, 4096),
+                      (4096, 1024, 128), (11008 // 86 * 86, 256, 128), (2048, 11008, 128), (6144, 2048 * 11, 128)]:
+        qw, s, qz = synth.make_awq_weights(K, N, g, "f16", "A", seed=M * 13 + K + N)
+        x = synth.make_activations(M, K, "f16", "A", seed=M + K)
+        b = synth.make_bias(N, "f16", 5)
+        packed = ops.awq_repack(*_dev(qw, s, qz))
+        assert packed is not None and packed.dtype == torch.uint8
+        y = to_np(ops.awq_gemm_repacked(to_torch(x, DEV), packed, K, N, g))
+        _, exact = c_oracle.gemm(x, qw, s, qz, want_exact=True)
+        assert_gemm_close(y, exact, "f16", what=f"repacked M={M} K={K} N={N} g={g}")
+        yb = ops.awq_gemm_repacked(to_torch(x, DEV), packed, K, N, g, to_torch(b, DEV))
+        assert torch.equal(yb, to_torch(y, DEV) + to_torch(b, DEV))
+    assert ops.awq_repack(*_dev(*synth.make_awq_weights(256, 64, 32, "f16", "A", 1))) is None        # g = 32: not supported
+    assert ops.awq_repack(*_dev(*synth.make_awq_weights(256, 64, 128, "bf16", "A", 1))) is None      # bf16: not supported
+
+
+def test_gemm_repacked_one_hot_rows_bit_exact_full_shape(ops):
+    K, N, g = 4096, 11008, 128
+    qw, s, qz = _dev(*synth.make_awq_weights(K, N, g, "f16", "F", 4243))
+    W = ops.awq_dequantize(qw, s, qz)
+    packed = ops.awq_repack(qw, s, qz)
+    rows = [0, 1, 127, 128, 2047, 2048, 4095, 31, 32, 33, 1000, 3000, 4064, 555, 77, 4094]
+    x = torch.zeros(len(rows), K, dtype=torch.float16, device=DEV)
+    for m, k in enumerate(rows):
+        x[m, k] = 1.0
+    for M in (1, 7, 16):
+        assert torch.equal(ops.awq_gemm_repacked(x[:M], packed, K, N, g), W[rows[:M]]), f"M={M}"
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
 def test_gemm_tiled_vs_oracle(ops, dt):
     """LDS-tiled MFMA kernel (prefill shapes): ragged M and N against the 128 x 128 tile, several K steps,
     g = 32 / 64 / 128 / K, more tiles than one XCD round."""

@@ -288,6 +288,68 @@ static int cmd_stamps(int argc, char** argv) {
   return 0;
 }
 
+// decode GEMV on the repacked (MFMA-fragment-major) layout
+static int cmd_rgemm(int argc, char** argv) {
+  if (argc < 6) { fprintf(stderr, "usage: kbench rgemm M K N g [sets] [iters] [graph]\n"); return 2; }
+  const int M = atoi(argv[2]), K = atoi(argv[3]), N = atoi(argv[4]), g = atoi(argv[5]);
+  const int sets = argc > 6 ? atoi(argv[6]) : 16;
+  const int iters = argc > 7 ? atoi(argv[7]) : 400;
+  const int use_graph = argc > 8 ? atoi(argv[8]) : 1;
+  const size_t pbytes = awq_repacked_bytes(K, N, g, AWQ_DTYPE_F16);
+  if (!pbytes) { fprintf(stderr, "shape not supported by the repacked path\n"); return 1; }
+  hipStream_t st; CK(hipStreamCreate(&st));
+  std::vector<void*> packed(sets);
+  {
+    auto w = make_weights(1, K, N, g, AWQ_DTYPE_F16);
+    for (int i = 0; i < sets; ++i) {
+      CK(hipMalloc(&packed[i], pbytes));
+      fill_u32(w[0].qw, (size_t)K * N / 8);       // fresh random nibbles per set
+      int rc = awq_repack(w[0].qw, w[0].sc, w[0].qz, packed[i], K, N, g, AWQ_DTYPE_F16, st);
+      if (rc) { fprintf(stderr, "awq_repack: %s\n", awq_hip_status_string(rc)); return 1; }
+      CK(hipStreamSynchronize(st));
+    }
+  }
+  void *x, *y;
+  CK(hipMalloc(&x, (size_t)M * K * 2)); fill_scales(x, (size_t)M * K, AWQ_DTYPE_F16, -1.f, 1.f);
+  CK(hipMalloc(&y, (size_t)M * N * 2));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto launch = [&](int i) {
+    int rc = awq_gemm_repacked(x, K, packed[i % sets], nullptr, y, M, K, N, g, AWQ_DTYPE_F16, st);
+    if (rc) { fprintf(stderr, "awq_gemm_repacked: %s\n", awq_hip_status_string(rc)); exit(1); }
+  };
+  for (int i = 0; i < 2 * sets; ++i) launch(i);
+  CK(hipStreamSynchronize(st));
+  float ms = 0;
+  if (use_graph) {
+    hipGraph_t graph; hipGraphExec_t exec;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+    for (int i = 0; i < sets; ++i) launch(i);
+    CK(hipStreamEndCapture(st, &graph));
+    CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    const int reps = (iters + sets - 1) / sets;
+    for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(exec, st));
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < reps; ++i) CK(hipGraphLaunch(exec, st));
+    CK(hipEventRecord(e1, st));
+    CK(hipStreamSynchronize(st));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= (float)(reps * sets);
+  } else {
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) launch(i);
+    CK(hipEventRecord(e1, st));
+    CK(hipStreamSynchronize(st));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= (float)iters;
+  }
+  const double us = ms * 1e3;
+  const double bytes = (double)K * N / 2 + (double)(K / g) * N / 2 + (double)(K / g) * N * 2 + (double)M * K * 2 + (double)M * N * 2;
+  printf("rgemm M=%d K=%d N=%d g=%d sets=%d graph=%d : %9.3f us  %8.1f GB/s (algorithmic)  %8.2f TFLOP/s\n", M, K, N, g, sets, use_graph, us,
+         bytes / us / 1e3, 2.0 * M * K * N / us / 1e6);
+  return 0;
+}
+
 static int cmd_dequant(int argc, char** argv) {
   if (argc < 6) { fprintf(stderr, "usage: kbench dequant K N g dtype [sets] [iters]\n"); return 2; }
   const int K = atoi(argv[2]), N = atoi(argv[3]), g = atoi(argv[4]), dtype = atoi(argv[5]);
@@ -322,6 +384,7 @@ int main(int argc, char** argv) {
   if (cmd == "gemm") return cmd_gemm(argc, argv);
   if (cmd == "dequant") return cmd_dequant(argc, argv);
   if (cmd == "stamps") return cmd_stamps(argc, argv);
+  if (cmd == "rgemm") return cmd_rgemm(argc, argv);
   if (cmd == "read") return cmd_read(argc, argv);
   fprintf(stderr, "unknown command %s\n", argv[1]);
   return 2;
