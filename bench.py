@@ -9,7 +9,10 @@ Workload (BASELINE.json configs[1], the decode shape): awq_gemm at M = 1, K = 40
 g = 128, fp16.  One STEP = one column-parallel AWQ linear followed by one row-parallel AWQ linear,
 each rank holding a full 4096 x 11008 shard (weak scaling: the TP=N layer is N times wider), i.e.
 two fused int4 GEMV launches per rank and, for N > 1, one RCCL all-reduce of the [M, 11008] fp16
-partial sums.  Weights rotate through `--sets` distinct copies (> 2x the 256 MiB Infinity Cache) so
+partial sums.  The linears are this package's AWQLinearMethod as deployed: at load time
+(process_weights_after_loading) the weights get a one-time MFMA-fragment-major copy and decode batches
+run the kernel on that copy; the drop-in op on the checkpoint layout (`sgl_kernel.awq_gemm`) is timed
+beside it and reported as `config.awq_gemm_op_checkpoint_layout`.  Weights rotate through `--sets` distinct copies (> 2x the 256 MiB Infinity Cache) so
 the stream comes from HBM, not from cache; the cache-hot number is reported beside it.  Steps are
 replayed from a captured HIP graph (the decode path of the reference replays graphs too), so the
 timed region contains exactly K steps of device work and no Python.
@@ -35,7 +38,8 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s 
 # HBM bytes per M=1 launch from the PMC counters (separate rocprofv3 --pmc passes of tools/kbench, files
 # profiles/r01_pmc_{fetch,write}_size_gemv_m1.csv): FETCH_SIZE 11,870.5 KiB x 2 (gfx950 reports half of a
 # wide coalesced read stream; calibrated on a 22.5 MB linear read) + WRITE_SIZE 513.75 KiB
-PMC_TRAFFIC_BYTES_M1 = int((2 * 11870.5 + 513.75) * 1024)
+PMC_TRAFFIC_BYTES_M1_CHECKPOINT_LAYOUT = int((2 * 11870.5 + 513.75) * 1024)   # gemm_skinny_kernel (awq_gemm op)
+PMC_TRAFFIC_BYTES_M1 = None    # gemv_repacked_kernel: filled in from profiles/r01_pmc_*_repacked.csv once collected
 MFMA_PEAK_TFLOPS = 2500.0       # dense fp16/bf16
 
 
@@ -224,6 +228,29 @@ def main():
         hot = ev_hot / 500
         cols, rows, sets, graphs = saved[0], saved[1], saved[2], saved[3]
 
+    # the drop-in op on the checkpoint layout, same rotation of weight sets (N = 1 only)
+    op_us = None
+    if rank == 0 and world == 1 and M <= 16:
+        def op_pass():
+            for i in range(sets):
+                ops.awq_gemm(x_col, cols[i].qweight, cols[i].scales, cols[i].qzeros, 1)
+        op_pass()
+        torch.cuda.synchronize()
+        g_op = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_op):
+            op_pass()
+        for _ in range(3):
+            g_op.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        reps = max(1, 1000 // sets)
+        for _ in range(reps):
+            g_op.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        op_us = e0.elapsed_time(e1) * 1e3 / (reps * sets)
+
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -242,7 +269,12 @@ def main():
         "config": {"workload": f"awq_gemm M={M} K={K_DIM} N={N_DIM} g={GROUP} fp16 (BASELINE configs[1]); step = column-parallel + "
                                f"row-parallel AWQ linear per rank" + (" + RCCL all-reduce [M,11008] fp16" if world > 1 else ""),
                    "weight_sets": sets, "graph_replay": use_graph, "parallelism": f"tp{world}",
-                   "tflops": round(world * flops_step * args.steps / wall / 1e12, 3)},
+                   "tflops": round(world * flops_step * args.steps / wall / 1e12, 3),
+                   "weight_layout": "MFMA-fragment-major copy made once at load (awq_repack); checkpoint tensors kept",
+                   "awq_gemm_op_checkpoint_layout": None if op_us is None else {
+                       "us_per_launch": round(op_us, 3), "GBps": round(algorithmic_bytes(M) / op_us / 1e3, 1),
+                       "frac_of_8TBps": round(algorithmic_bytes(M) / op_us / 1e3 / HBM_PEAK_GBPS, 4),
+                       "pmc_traffic_bytes": PMC_TRAFFIC_BYTES_M1_CHECKPOINT_LAYOUT if M == 1 else None}},
     }
     if world == 1:
         ach = algorithmic_bytes(M) / per_launch / 1e9
@@ -252,7 +284,7 @@ def main():
                                "frac": round(ach / HBM_PEAK_GBPS, 4),
                                "traffic": PMC_TRAFFIC_BYTES_M1 if M == 1 else None,
                                "traffic_note": "bytes per launch, rocprofv3 PMC passes committed under profiles/ (not collected live)",
-                               "kernel": "gemm_skinny_kernel", "us_per_launch": round(per_launch * 1e6, 3),
+                               "kernel": "gemv_repacked_kernel", "us_per_launch": round(per_launch * 1e6, 3),
                                "cache_hot_GBps": round(algorithmic_bytes(M) / (hot / launches_per_step) / 1e9, 1) if hot else None}
         else:
             tf = 2 * M * K_DIM * N_DIM / per_launch / 1e12

@@ -19,12 +19,13 @@
 //                               fp16(1024 + zero).  Columns >= N are padded with scale 0.
 // A workgroup owns G consecutive column groups (a strip of 16 G columns) for ALL of K; its 8 waves take
 // consecutive k-block ranges and are summed in fixed order through LDS; y is written directly.
+#include <cstdlib>
+
 #include "awq_device.h"
 #include "awq_kernels.h"
 
 namespace awq {
 
-constexpr int kRpWaves = 8;
 constexpr int kRpMaxG = 8;
 
 // ------------------------------------------------------------------------------------------ repack
@@ -90,13 +91,16 @@ struct RpBlock {            // one k-block (128 rows) of a strip, in registers
   u32x4_t xa[4];            // x fragments of the 4 k-steps
 };
 
-template <int G>
+template <int G, bool NT>
 __device__ __forceinline__ void rp_load(RpBlock& b, const u32x4_t* __restrict__ qw_r, const uint32_t* __restrict__ zs_r,
                                         const uint16_t* __restrict__ x, int64_t ldx, int cg0, int KB, int groups, int g, int kb,
                                         int lane, int xr) {
   const int q = lane >> 4, r = lane & 15;
 #pragma unroll
-  for (int c = 0; c < G; ++c) b.w[c] = qw_r[((size_t)(cg0 + c) * KB + kb) * 64 + lane];
+  for (int c = 0; c < G; ++c) {
+    const u32x4_t* p = qw_r + ((size_t)(cg0 + c) * KB + kb) * 64 + lane;
+    b.w[c] = NT ? __builtin_nontemporal_load(p) : *p;      // streamed once: keep it out of the caches' way
+  }
   const int grp = (kb * 128) / g;                      // g >= 128 here (smaller groups take the per-k-step path below)
 #pragma unroll
   for (int c = 0; c < G; ++c) b.zs[c] = zs_r[((size_t)(cg0 + c) * groups + grp) * 16 + r];
@@ -122,13 +126,13 @@ __device__ __forceinline__ void rp_compute(const RpBlock& b, float4_t (&acc)[kRp
 
 // T = k-blocks per wave when it is small enough to issue every load up front (straight-line code, exact
 // counted waits); T == 0: any count, double-buffered loop.
-template <int G, int T>
-__global__ __launch_bounds__(kRpWaves * 64, 2) void gemv_repacked_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+template <int G, int T, int W, bool NT>
+__global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(const uint16_t* __restrict__ x, int64_t ldx,
                                                                           const u32x4_t* __restrict__ qw_r,
                                                                           const uint32_t* __restrict__ zs_r,
                                                                           const void* __restrict__ bias, void* __restrict__ y,
                                                                           int M, int K, int N, int g, int NG, int per_wave) {
-  extern __shared__ __attribute__((aligned(16))) float red[];    // [kRpWaves][M][16 G]
+  extern __shared__ __attribute__((aligned(16))) float red[];    // [W][M][16 G]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, r = lane & 15;
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(kRpWaves * 64, 2) void gemv_repacked_kernel(const u
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const int kb = kb_begin + t < KB ? kb_begin + t : KB - 1;         // clamped: re-read, then weighted by x = 0
-      rp_load<G>(buf[t], qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
+      rp_load<G, NT>(buf[t], qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -167,17 +171,17 @@ __global__ __launch_bounds__(kRpWaves * 64, 2) void gemv_repacked_kernel(const u
     // <= 3-block tail are conditional
     RpBlock A, B;
     int kb = kb_begin;
-    if (kb < kb_end) rp_load<G>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
-    if (kb + 1 < kb_end) rp_load<G>(B, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 1, lane, xr);
+    if (kb < kb_end) rp_load<G, NT>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
+    if (kb + 1 < kb_end) rp_load<G, NT>(B, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 1, lane, xr);
     while (kb + 3 < kb_end) {
       rp_compute<G>(A, acc);
-      rp_load<G>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 2, lane, xr);
+      rp_load<G, NT>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 2, lane, xr);
       rp_compute<G>(B, acc);
-      rp_load<G>(B, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 3, lane, xr);
+      rp_load<G, NT>(B, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 3, lane, xr);
       kb += 2;
     }
     if (kb < kb_end) rp_compute<G>(A, acc);
-    if (kb + 2 < kb_end) rp_load<G>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 2, lane, xr);
+    if (kb + 2 < kb_end) rp_load<G, NT>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 2, lane, xr);
     if (kb + 1 < kb_end) rp_compute<G>(B, acc);
     if (kb + 2 < kb_end) rp_compute<G>(A, acc);
   }
@@ -192,13 +196,13 @@ __global__ __launch_bounds__(kRpWaves * 64, 2) void gemv_repacked_kernel(const u
       if (m < M) red[((size_t)wave * M + m) * SW + c * 16 + r] = acc[c][i];
     }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < M * SW; idx += kRpWaves * 64) {
+  for (int idx = threadIdx.x; idx < M * SW; idx += W * 64) {
     const int m = idx / SW, col = idx - m * SW;
     const int n = cg0 * 16 + col;
     if (n >= N) continue;
     float v = red[(size_t)m * SW + col];
 #pragma unroll
-    for (int w = 1; w < kRpWaves; ++w) v += red[((size_t)w * M + m) * SW + col];
+    for (int w = 1; w < W; ++w) v += red[((size_t)w * M + m) * SW + col];
     store_output<AWQ_DTYPE_F16>(y, (size_t)m * N + n, v, bias, n);
   }
 }
@@ -229,22 +233,38 @@ int launch_repack(const int32_t* qweight, const void* scales, const int32_t* qze
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
-template <int G>
+template <int G, int W, bool NT>
 static void rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wave, int nwg, size_t lds) {
   const u32x4_t* qw_r = (const u32x4_t*)packed;
   const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
-  dim3 grid(nwg), block(kRpWaves * 64);
-#define RP_GO(TT)                                                                                                           \
-  hipLaunchKernelGGL((gemv_repacked_kernel<G, TT>), grid, block, lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r, a.bias, \
+  dim3 grid(nwg), block(W * 64);
+#define RP_GO(TT)                                                                                                                 \
+  hipLaunchKernelGGL((gemv_repacked_kernel<G, TT, W, NT>), grid, block, lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r, a.bias, \
                      a.y, a.M, a.K, a.N, a.g, NG, per_wave)
   switch (per_wave) {
     case 1: RP_GO(1); break;
     case 2: RP_GO(2); break;
     case 3: RP_GO(3); break;
     case 4: RP_GO(4); break;
+    case 5: RP_GO(5); break;
+    case 6: RP_GO(6); break;
     default: RP_GO(0); break;
   }
 #undef RP_GO
+}
+
+template <int W, bool NT>
+static void rp_launch_g(int G, const GemmArgs& a, const void* packed, int NG, int per_wave, int nwg, size_t lds) {
+  switch (G) {
+    case 1: rp_launch<1, W, NT>(a, packed, NG, per_wave, nwg, lds); break;
+    case 2: rp_launch<2, W, NT>(a, packed, NG, per_wave, nwg, lds); break;
+    case 3: rp_launch<3, W, NT>(a, packed, NG, per_wave, nwg, lds); break;
+    case 4: rp_launch<4, W, NT>(a, packed, NG, per_wave, nwg, lds); break;
+    case 5: rp_launch<5, W, NT>(a, packed, NG, per_wave, nwg, lds); break;
+    case 6: rp_launch<6, W, NT>(a, packed, NG, per_wave, nwg, lds); break;
+    case 7: rp_launch<7, W, NT>(a, packed, NG, per_wave, nwg, lds); break;
+    default: rp_launch<8, W, NT>(a, packed, NG, per_wave, nwg, lds); break;
+  }
 }
 
 int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
@@ -255,19 +275,20 @@ int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
   if (G > NG) G = NG;
   const int nwg = (NG + G - 1) / G;
   const int KB = a.K / 128;
-  const int per_wave = (KB + kRpWaves - 1) / kRpWaves;
-  const size_t lds = (size_t)kRpWaves * a.M * 16 * G * sizeof(float);
+  // 16 waves + non-temporal weight loads for matrices that are streamed from HBM (measured 7.2 vs 8.3 us at
+  // 4096 x 11008); small ones (< 12 MB packed, largely L2 / Infinity-Cache resident) run better with 8 waves and
+  // default-policy loads (4.2 vs 4.7 us at 4096 x 4096).  AWQ_RP_WAVES / AWQ_RP_NT override for A/B runs.
+  const bool big = (size_t)a.K * a.N / 2 >= (12u << 20);
+  static const int env_waves = getenv("AWQ_RP_WAVES") ? atoi(getenv("AWQ_RP_WAVES")) : 0;
+  static const int env_nt = getenv("AWQ_RP_NT") ? atoi(getenv("AWQ_RP_NT")) : -1;
+  int W = env_waves == 16 || env_waves == 8 ? env_waves : (big ? 16 : 8);
+  const bool nt = env_nt >= 0 ? env_nt != 0 : big;
+  if ((size_t)W * a.M * 16 * G * sizeof(float) > 64 * 1024) W = 8;     // reduction scratch: 8 x 16 x 128 x 4 B = 64 KiB always fits
+  const int per_wave = (KB + W - 1) / W;
+  const size_t lds = (size_t)W * a.M * 16 * G * sizeof(float);
   if (lds > 64 * 1024) return AWQ_ERR_BAD_VARIANT;
-  switch (G) {
-    case 1: rp_launch<1>(a, packed, NG, per_wave, nwg, lds); break;
-    case 2: rp_launch<2>(a, packed, NG, per_wave, nwg, lds); break;
-    case 3: rp_launch<3>(a, packed, NG, per_wave, nwg, lds); break;
-    case 4: rp_launch<4>(a, packed, NG, per_wave, nwg, lds); break;
-    case 5: rp_launch<5>(a, packed, NG, per_wave, nwg, lds); break;
-    case 6: rp_launch<6>(a, packed, NG, per_wave, nwg, lds); break;
-    case 7: rp_launch<7>(a, packed, NG, per_wave, nwg, lds); break;
-    default: rp_launch<8>(a, packed, NG, per_wave, nwg, lds); break;
-  }
+  if (W == 16) { if (nt) rp_launch_g<16, true>(G, a, packed, NG, per_wave, nwg, lds); else rp_launch_g<16, false>(G, a, packed, NG, per_wave, nwg, lds); }
+  else { if (nt) rp_launch_g<8, true>(G, a, packed, NG, per_wave, nwg, lds); else rp_launch_g<8, false>(G, a, packed, NG, per_wave, nwg, lds); }
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
