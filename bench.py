@@ -39,7 +39,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s 
 # profiles/r01_pmc_{fetch,write}_size_gemv_m1.csv): FETCH_SIZE 11,870.5 KiB x 2 (gfx950 reports half of a
 # wide coalesced read stream; calibrated on a 22.5 MB linear read) + WRITE_SIZE 513.75 KiB
 PMC_TRAFFIC_BYTES_M1_CHECKPOINT_LAYOUT = int((2 * 11870.5 + 513.75) * 1024)   # gemm_skinny_kernel (awq_gemm op)
-PMC_TRAFFIC_BYTES_M1 = None    # gemv_repacked_kernel: filled in from profiles/r01_pmc_*_repacked.csv once collected
+PMC_TRAFFIC_BYTES_M1 = int((2 * 11812.0 + 21.5625) * 1024)                     # gemv_repacked_kernel (profiles/r01_pmc_*_repacked_m1.csv)
 MFMA_PEAK_TFLOPS = 2500.0       # dense fp16/bf16
 
 

@@ -87,7 +87,7 @@ class AWQLinearMethod(LinearMethodBase):
     """Linear method for AWQ (awq.py:352-451)."""
 
     # decode batches at or below this go to the repacked-layout kernel when a repacked copy exists
-    REPACKED_MAX_M = 16
+    REPACKED_MAX_M = 32
 
     def __init__(self, quant_config: AWQConfig, apply_mode: Optional[str] = None, repack: Optional[bool] = None):
         self.quant_config = quant_config
@@ -151,7 +151,10 @@ class AWQLinearMethod(LinearMethodBase):
         packed = getattr(layer, "awq_packed", None)
         if packed is not None and reshaped_x.shape[0] <= self.REPACKED_MAX_M and reshaped_x.shape[0] > 0:
             K = qweight.shape[0]
-            out = ops.awq_gemm_repacked(reshaped_x, packed, K, out_shape[-1], K // scales.shape[0], bias)
+            try:
+                out = ops.awq_gemm_repacked(reshaped_x, packed, K, out_shape[-1], K // scales.shape[0], bias)
+            except ops.AwqHipError:     # e.g. M = 32 on a very wide strip: reduction scratch over the LDS guard
+                out = ops.awq_linear(reshaped_x, qweight, scales, qzeros, bias)
         elif self.apply_mode == "fused":
             out = ops.awq_linear(reshaped_x, qweight, scales, qzeros, bias)
         else:

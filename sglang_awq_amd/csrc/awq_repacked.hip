@@ -85,16 +85,17 @@ __device__ __forceinline__ u32x4_t rp_dequant(uint32_t w, half2_t z1024, half2_t
   return (u32x4_t){as_u32(d0 * s2), as_u32(d1 * s2), as_u32(d2 * s2), as_u32(d3 * s2)};
 }
 
+constexpr int kRpMaxMT = 2;   // MFMA row tiles: M <= 16 * MT
 struct RpBlock {            // one k-block (128 rows) of a strip, in registers
   u32x4_t w[kRpMaxG];       // per column group: 4 dwords = 4 k-steps
   uint32_t zs[kRpMaxG];     // per column group: (1024 + z | s) of this lane's column
-  u32x4_t xa[4];            // x fragments of the 4 k-steps
+  u32x4_t xa[4][kRpMaxMT];  // x fragments of the 4 k-steps, per row tile
 };
 
-template <int G, bool NT>
+template <int G, bool NT, int MT>
 __device__ __forceinline__ void rp_load(RpBlock& b, const u32x4_t* __restrict__ qw_r, const uint32_t* __restrict__ zs_r,
                                         const uint16_t* __restrict__ x, int64_t ldx, int cg0, int KB, int groups, int g, int kb,
-                                        int lane, int xr) {
+                                        int lane, const int (&xr)[kRpMaxMT]) {
   const int q = lane >> 4, r = lane & 15;
 #pragma unroll
   for (int c = 0; c < G; ++c) {
@@ -105,11 +106,13 @@ __device__ __forceinline__ void rp_load(RpBlock& b, const u32x4_t* __restrict__ 
 #pragma unroll
   for (int c = 0; c < G; ++c) b.zs[c] = zs_r[((size_t)(cg0 + c) * groups + grp) * 16 + r];
 #pragma unroll
-  for (int d = 0; d < 4; ++d) b.xa[d] = *(const u32x4_t*)(x + (size_t)xr * ldx + kb * 128 + d * 32 + q * 8);
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) b.xa[d][mt] = *(const u32x4_t*)(x + (size_t)xr[mt] * ldx + kb * 128 + d * 32 + q * 8);
 }
 
-template <int G>
-__device__ __forceinline__ void rp_compute(const RpBlock& b, float4_t (&acc)[kRpMaxG]) {
+template <int G, int MT>
+__device__ __forceinline__ void rp_compute(const RpBlock& b, float4_t (&acc)[kRpMaxMT][kRpMaxG]) {
   const half2_t c960 = {(half_t)960.f, (half_t)960.f};
 #pragma unroll
   for (int c = 0; c < G; ++c) {
@@ -119,14 +122,16 @@ __device__ __forceinline__ void rp_compute(const RpBlock& b, float4_t (&acc)[kRp
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       const u32x4_t frag = rp_dequant(b.w[c][d], z1024, z64, s2);
-      acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, b.xa[d]), __builtin_bit_cast(half8_t, frag), acc[c], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)   // the dequantised fragment is shared by every row tile
+        acc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, b.xa[d][mt]), __builtin_bit_cast(half8_t, frag), acc[mt][c], 0, 0, 0);
     }
   }
 }
 
 // T = k-blocks per wave when it is small enough to issue every load up front (straight-line code, exact
 // counted waits); T == 0: any count, double-buffered loop.
-template <int G, int T, int W, bool NT>
+template <int G, int T, int W, bool NT, int MT>
 __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(const uint16_t* __restrict__ x, int64_t ldx,
                                                                           const u32x4_t* __restrict__ qw_r,
                                                                           const uint32_t* __restrict__ zs_r,
@@ -139,11 +144,15 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
   const int KB = K / 128, groups = K / g;
   int cg0 = blockIdx.x * G;
   if (cg0 + G > NG) cg0 = NG - G;                      // last strip overlaps its neighbour (same values written twice)
-  const int xr = r < M ? r : M - 1;
-
-  float4_t acc[kRpMaxG];
+  int xr[kRpMaxMT];
 #pragma unroll
-  for (int c = 0; c < G; ++c) acc[c] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  for (int mt = 0; mt < kRpMaxMT; ++mt) xr[mt] = mt * 16 + r < M ? mt * 16 + r : M - 1;
+
+  float4_t acc[kRpMaxMT][kRpMaxG];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int c = 0; c < G; ++c) acc[mt][c] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
   const int kb_begin = wave * per_wave;
   int kb_end = kb_begin + per_wave;
@@ -154,16 +163,18 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const int kb = kb_begin + t < KB ? kb_begin + t : KB - 1;         // clamped: re-read, then weighted by x = 0
-      rp_load<G, NT>(buf[t], qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
+      rp_load<G, NT, MT>(buf[t], qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       if (kb_begin + t >= KB) {
 #pragma unroll
-        for (int d = 0; d < 4; ++d) buf[t].xa[d] = (u32x4_t){0u, 0u, 0u, 0u};
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) buf[t].xa[d][mt] = (u32x4_t){0u, 0u, 0u, 0u};
       }
-      rp_compute<G>(buf[t], acc);
+      rp_compute<G, MT>(buf[t], acc);
       __builtin_amdgcn_sched_barrier(0);
     }
   } else {
@@ -171,30 +182,32 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
     // <= 3-block tail are conditional
     RpBlock A, B;
     int kb = kb_begin;
-    if (kb < kb_end) rp_load<G, NT>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
-    if (kb + 1 < kb_end) rp_load<G, NT>(B, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 1, lane, xr);
+    if (kb < kb_end) rp_load<G, NT, MT>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
+    if (kb + 1 < kb_end) rp_load<G, NT, MT>(B, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 1, lane, xr);
     while (kb + 3 < kb_end) {
-      rp_compute<G>(A, acc);
-      rp_load<G, NT>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 2, lane, xr);
-      rp_compute<G>(B, acc);
-      rp_load<G, NT>(B, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 3, lane, xr);
+      rp_compute<G, MT>(A, acc);
+      rp_load<G, NT, MT>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 2, lane, xr);
+      rp_compute<G, MT>(B, acc);
+      rp_load<G, NT, MT>(B, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 3, lane, xr);
       kb += 2;
     }
-    if (kb < kb_end) rp_compute<G>(A, acc);
-    if (kb + 2 < kb_end) rp_load<G, NT>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 2, lane, xr);
-    if (kb + 1 < kb_end) rp_compute<G>(B, acc);
-    if (kb + 2 < kb_end) rp_compute<G>(A, acc);
+    if (kb < kb_end) rp_compute<G, MT>(A, acc);
+    if (kb + 2 < kb_end) rp_load<G, NT, MT>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 2, lane, xr);
+    if (kb + 1 < kb_end) rp_compute<G, MT>(B, acc);
+    if (kb + 2 < kb_end) rp_compute<G, MT>(A, acc);
   }
 
   // D[m = 4q + i][n = r] per column group -> LDS, summed over the 8 waves in fixed order
   const int SW = 16 * G;
 #pragma unroll
-  for (int c = 0; c < G; ++c)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = 4 * q + i;
-      if (m < M) red[((size_t)wave * M + m) * SW + c * 16 + r] = acc[c][i];
-    }
+    for (int c = 0; c < G; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = mt * 16 + 4 * q + i;
+        if (m < M) red[((size_t)wave * M + m) * SW + c * 16 + r] = acc[mt][c][i];
+      }
   __syncthreads();
   for (int idx = threadIdx.x; idx < M * SW; idx += W * 64) {
     const int m = idx / SW, col = idx - m * SW;
@@ -233,42 +246,46 @@ int launch_repack(const int32_t* qweight, const void* scales, const int32_t* qze
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
-template <int G, int W, bool NT>
+template <int G, int W, bool NT, int MT>
 static void rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wave, int nwg, size_t lds) {
   const u32x4_t* qw_r = (const u32x4_t*)packed;
   const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
   dim3 grid(nwg), block(W * 64);
 #define RP_GO(TT)                                                                                                                 \
-  hipLaunchKernelGGL((gemv_repacked_kernel<G, TT, W, NT>), grid, block, lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r, a.bias, \
+  hipLaunchKernelGGL((gemv_repacked_kernel<G, TT, W, NT, MT>), grid, block, lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r, a.bias, \
                      a.y, a.M, a.K, a.N, a.g, NG, per_wave)
-  switch (per_wave) {
-    case 1: RP_GO(1); break;
-    case 2: RP_GO(2); break;
-    case 3: RP_GO(3); break;
-    case 4: RP_GO(4); break;
-    case 5: RP_GO(5); break;
-    case 6: RP_GO(6); break;
-    default: RP_GO(0); break;
+  if constexpr (MT == 1) {
+    switch (per_wave) {
+      case 1: RP_GO(1); break;
+      case 2: RP_GO(2); break;
+      case 3: RP_GO(3); break;
+      case 4: RP_GO(4); break;
+      case 5: RP_GO(5); break;
+      case 6: RP_GO(6); break;
+      default: RP_GO(0); break;
+    }
+  } else {                       // two row tiles: fewer specialisations (registers, build time)
+    if (per_wave == 4) RP_GO(4); else RP_GO(0);
   }
 #undef RP_GO
 }
 
-template <int W, bool NT>
+template <int W, bool NT, int MT>
 static void rp_launch_g(int G, const GemmArgs& a, const void* packed, int NG, int per_wave, int nwg, size_t lds) {
   switch (G) {
-    case 1: rp_launch<1, W, NT>(a, packed, NG, per_wave, nwg, lds); break;
-    case 2: rp_launch<2, W, NT>(a, packed, NG, per_wave, nwg, lds); break;
-    case 3: rp_launch<3, W, NT>(a, packed, NG, per_wave, nwg, lds); break;
-    case 4: rp_launch<4, W, NT>(a, packed, NG, per_wave, nwg, lds); break;
-    case 5: rp_launch<5, W, NT>(a, packed, NG, per_wave, nwg, lds); break;
-    case 6: rp_launch<6, W, NT>(a, packed, NG, per_wave, nwg, lds); break;
-    case 7: rp_launch<7, W, NT>(a, packed, NG, per_wave, nwg, lds); break;
-    default: rp_launch<8, W, NT>(a, packed, NG, per_wave, nwg, lds); break;
+    case 1: rp_launch<1, W, NT, MT>(a, packed, NG, per_wave, nwg, lds); break;
+    case 2: rp_launch<2, W, NT, MT>(a, packed, NG, per_wave, nwg, lds); break;
+    case 3: rp_launch<3, W, NT, MT>(a, packed, NG, per_wave, nwg, lds); break;
+    case 4: rp_launch<4, W, NT, MT>(a, packed, NG, per_wave, nwg, lds); break;
+    case 5: rp_launch<5, W, NT, MT>(a, packed, NG, per_wave, nwg, lds); break;
+    case 6: rp_launch<6, W, NT, MT>(a, packed, NG, per_wave, nwg, lds); break;
+    case 7: rp_launch<7, W, NT, MT>(a, packed, NG, per_wave, nwg, lds); break;
+    default: rp_launch<8, W, NT, MT>(a, packed, NG, per_wave, nwg, lds); break;
   }
 }
 
 int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
-  if (!repacked_supported(a.K, a.N, a.g, a.dtype) || a.M < 1 || a.M > 16 || a.ldx % 8 || (((uintptr_t)a.x) & 15)) return AWQ_ERR_BAD_VARIANT;
+  if (!repacked_supported(a.K, a.N, a.g, a.dtype) || a.M < 1 || a.M > 16 * kRpMaxMT || a.ldx % 8 || (((uintptr_t)a.x) & 15)) return AWQ_ERR_BAD_VARIANT;
   const int NG = rp_groups(a.N);
   int G = (NG + 255) / 256;                            // one strip per CU
   if (G > kRpMaxG) G = kRpMaxG;
@@ -283,12 +300,14 @@ int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
   static const int env_nt = getenv("AWQ_RP_NT") ? atoi(getenv("AWQ_RP_NT")) : -1;
   int W = env_waves == 16 || env_waves == 8 ? env_waves : (big ? 16 : 8);
   const bool nt = env_nt >= 0 ? env_nt != 0 : big;
-  if ((size_t)W * a.M * 16 * G * sizeof(float) > 64 * 1024) W = 8;     // reduction scratch: 8 x 16 x 128 x 4 B = 64 KiB always fits
+  const bool two_tiles = a.M > 16;
+  if (two_tiles || (size_t)W * a.M * 16 * G * sizeof(float) > 64 * 1024) W = 8;
   const int per_wave = (KB + W - 1) / W;
   const size_t lds = (size_t)W * a.M * 16 * G * sizeof(float);
-  if (lds > 64 * 1024) return AWQ_ERR_BAD_VARIANT;
-  if (W == 16) { if (nt) rp_launch_g<16, true>(G, a, packed, NG, per_wave, nwg, lds); else rp_launch_g<16, false>(G, a, packed, NG, per_wave, nwg, lds); }
-  else { if (nt) rp_launch_g<8, true>(G, a, packed, NG, per_wave, nwg, lds); else rp_launch_g<8, false>(G, a, packed, NG, per_wave, nwg, lds); }
+  if (lds > 64 * 1024) return AWQ_ERR_BAD_VARIANT;                      // (M = 32 with 8-group strips: callers fall back to awq_gemm)
+  if (two_tiles) rp_launch_g<8, true, 2>(G, a, packed, NG, per_wave, nwg, lds);
+  else if (W == 16) { if (nt) rp_launch_g<16, true, 1>(G, a, packed, NG, per_wave, nwg, lds); else rp_launch_g<16, false, 1>(G, a, packed, NG, per_wave, nwg, lds); }
+  else { if (nt) rp_launch_g<8, true, 1>(G, a, packed, NG, per_wave, nwg, lds); else rp_launch_g<8, false, 1>(G, a, packed, NG, per_wave, nwg, lds); }
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 

@@ -25,6 +25,7 @@ from typing import Optional
 import torch
 
 from . import _lib
+from ._lib import AwqHipError  # noqa: F401  (re-exported)
 
 _DTYPE_CODE = {torch.float16: _lib.DTYPE_F16, torch.bfloat16: _lib.DTYPE_BF16, torch.float32: _lib.DTYPE_F32}
 _WORKSPACE_BYTES = 4096 + (32 << 20)       # counters + the slab budget awq_gemm_workspace_bytes() never exceeds
