@@ -1,0 +1,30 @@
+/*
+ * awq_aux.h — fused neighbours of the AWQ linears used by the decode harness.  NOT part of the
+ * drop-in operator boundary (that is awq_hip.h): these are the elementwise steps either side of the four
+ * projections of a Llama layer in the reference model (python/sglang/srt/models/llama.py:94-106, :188-199),
+ * each as one small launch.  fp16 tensors, dense row-major, device pointers, hipStream_t as void*;
+ * return 0 or a negative awq_status (awq_hip.h).
+ */
+#ifndef AWQ_AUX_H_
+#define AWQ_AUX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* h[rows, H] += delta (if delta != NULL, written back) ; out = rmsnorm(h) * w   (layers/layernorm.py RMSNorm with residual) */
+int awq_aux_add_rmsnorm(void* h, const void* delta, const void* w, void* out, int64_t rows, int64_t H, float eps, void* stream);
+
+/* neox rotary embedding in place on the q / k heads of qkv[B, (Hq + 2 Hkv) D]; k, v of the token -> caches [B, Hkv, S, D] at pos[b] */
+int awq_aux_rope_kv(void* qkv, const int64_t* pos, const float* cos_table, const float* sin_table, void* k_cache, void* v_cache,
+                    int64_t B, int64_t Hq, int64_t Hkv, int64_t D, int64_t S, void* stream);
+
+/* act[rows, I] = silu(gate_up[:, :I]) * gate_up[:, I:]   (layers/activation.py SiluAndMul) */
+int awq_aux_silu_mul(const void* gate_up, void* act, int64_t rows, int64_t I, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AWQ_AUX_H_ */

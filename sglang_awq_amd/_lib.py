@@ -27,6 +27,8 @@ EXPORTS = (
     "awq_repack",
     "awq_gemm_repacked",
 )
+# include/awq_aux.h (decode-harness helpers, not part of the operator boundary)
+AUX_EXPORTS = ("awq_aux_add_rmsnorm", "awq_aux_rope_kv", "awq_aux_silu_mul")
 ABI_VERSION = 1
 
 DTYPE_F16, DTYPE_BF16, DTYPE_F32 = 0, 1, 2
@@ -73,6 +75,12 @@ def _bind(L):
     L.awq_repack.restype = ci
     L.awq_gemm_repacked.argtypes = [vp, i64, vp, vp, vp, i64, i64, i64, i64, ci, vp]
     L.awq_gemm_repacked.restype = ci
+    L.awq_aux_add_rmsnorm.argtypes = [vp, vp, vp, vp, i64, i64, ctypes.c_float, vp]
+    L.awq_aux_add_rmsnorm.restype = ci
+    L.awq_aux_rope_kv.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp]
+    L.awq_aux_rope_kv.restype = ci
+    L.awq_aux_silu_mul.argtypes = [vp, vp, i64, i64, vp]
+    L.awq_aux_silu_mul.restype = ci
 
 
 def load():
@@ -91,7 +99,7 @@ def load():
                 L = ctypes.CDLL(LIB_PATH)
             except OSError as e:
                 raise AwqHipError(f"cannot load {LIB_PATH}: {e}") from e
-            missing = [s for s in EXPORTS if not hasattr(L, s)]
+            missing = [s for s in EXPORTS + AUX_EXPORTS if not hasattr(L, s)]
             if missing:
                 raise AwqHipError(f"{LIB_PATH} lacks symbols {missing}")
             _bind(L)

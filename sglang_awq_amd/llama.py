@@ -88,6 +88,24 @@ class LlamaDecoderLayer(torch.nn.Module):
         self.register_buffer("k_cache", torch.zeros(max_batch, self.num_kv_heads, max_seq, self.head_dim, dtype=dtype), persistent=False)
         self.register_buffer("v_cache", torch.zeros(max_batch, self.num_kv_heads, max_seq, self.head_dim, dtype=dtype), persistent=False)
 
+    def forward_fused(self, h, delta, pos, cos_table, sin_table, mask):
+        """Same layer with the elementwise neighbours fused (aux_ops): h is the residual stream (updated in place),
+        delta the previous layer's MLP output still to be added.  Returns this layer's MLP output (the next delta)."""
+        from . import aux_ops
+
+        B = h.shape[0]
+        x = aux_ops.add_rmsnorm(h, delta, self.input_layernorm, self.cfg.rms_norm_eps)
+        qkv, _ = self.qkv_proj(x)
+        aux_ops.rope_kv(qkv, pos, cos_table, sin_table, self.k_cache, self.v_cache, self.num_heads, self.num_kv_heads, self.head_dim)
+        q = qkv[:, :self.q_size].view(B, self.num_heads, 1, self.head_dim)
+        attn = F.scaled_dot_product_attention(q, self.k_cache[:B], self.v_cache[:B], attn_mask=mask,
+                                              enable_gqa=self.num_heads != self.num_kv_heads)
+        o, _ = self.o_proj(attn.reshape(B, self.q_size))
+        x = aux_ops.add_rmsnorm(h, o, self.post_attention_layernorm, self.cfg.rms_norm_eps)
+        gu, _ = self.gate_up_proj(x)
+        d, _ = self.down_proj(aux_ops.silu_mul(gu))
+        return d
+
     def forward(self, h: torch.Tensor, pos: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         B = h.shape[0]
         x = rms_norm(h, self.input_layernorm, self.cfg.rms_norm_eps)
@@ -117,6 +135,7 @@ class LlamaForCausalLM(torch.nn.Module):
     def __init__(self, cfg: LlamaConfig, quant: AWQConfig, max_batch: int = 32, max_seq: int = 512, dtype: torch.dtype = torch.float16):
         super().__init__()
         self.cfg, self.max_batch, self.max_seq, self.dtype = cfg, max_batch, max_seq, dtype
+        self.fused_aux = True        # fused RMSNorm / RoPE+KV / SiLU-mul kernels (aux_ops); False = plain torch ops
         self.embed_tokens = torch.nn.Parameter(torch.zeros(cfg.vocab_size, cfg.hidden_size, dtype=dtype), requires_grad=False)
         self.layers = torch.nn.ModuleList(LlamaDecoderLayer(cfg, quant, i, max_batch, max_seq, dtype) for i in range(cfg.num_hidden_layers))
         self.norm = torch.nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype), requires_grad=False)
@@ -151,6 +170,16 @@ class LlamaForCausalLM(torch.nn.Module):
         return self.logits(tokens, pos).argmax(-1)
 
     def logits(self, tokens: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+        if self.fused_aux and self.dtype == torch.float16:
+            from . import aux_ops
+
+            h = self.embed_tokens[tokens]                       # residual stream, updated in place by add_rmsnorm
+            mask = (self.arange_seq.view(1, 1, 1, -1) <= pos.view(-1, 1, 1, 1))
+            delta = None
+            for layer in self.layers:
+                delta = layer.forward_fused(h, delta, pos, self.cos_table, self.sin_table, mask)
+            h = aux_ops.add_rmsnorm(h, delta, self.norm, self.cfg.rms_norm_eps)
+            return torch.matmul(h, self.lm_head.t())
         h = self.embed_tokens[tokens]
         cos = self.cos_table[pos].unsqueeze(1)
         sin = self.sin_table[pos].unsqueeze(1)

@@ -78,13 +78,21 @@ def test_tiny_llama_decode_matches_fp32_reference_and_graph_replay():
     tokens = torch.tensor([5, 17, 300], device=DEV)
     pos = torch.tensor([0, 0, 0], device=DEV)
     with torch.no_grad():
-        for step in range(4):
-            got = model.logits(tokens, pos).float()
-            want = _ref_step(model, W, tokens, pos, kc, vc)
-            scale = want.abs().max().item()
-            assert (got - want).abs().max().item() <= 2e-2 * scale + 2e-2, f"step {step}"
-            tokens = want.argmax(-1)
-            pos = pos + 1
+        for fused in (False, True):              # plain torch neighbours, then the fused aux kernels
+            model.fused_aux = fused
+            for layer in model.layers:
+                layer.k_cache.zero_(); layer.v_cache.zero_()
+            for t_ in kc + vc:
+                t_.zero_()
+            tokens = torch.tensor([5, 17, 300], device=DEV)
+            pos = torch.tensor([0, 0, 0], device=DEV)
+            for step in range(4):
+                got = model.logits(tokens, pos).float()
+                want = _ref_step(model, W, tokens, pos, kc, vc)
+                scale = want.abs().max().item()
+                assert (got - want).abs().max().item() <= 2e-2 * scale + 2e-2, f"fused={fused} step {step}"
+                tokens = want.argmax(-1)
+                pos = pos + 1
 
     # graph replay produces the same token stream as eager stepping
     for layer in model.layers:

@@ -21,22 +21,23 @@ def lib():
     return _lib.load()
 
 
-def _header_functions():
-    text = open(os.path.join(ROOT, "include", "awq_hip.h")).read()
+def _header_functions(name="awq_hip.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(awq_[a-z_]+)\s*\(", text)))
 
 
 def test_header_and_export_list_agree(lib):
     assert _header_functions() == sorted(_lib.EXPORTS)
-    for sym in _lib.EXPORTS:
+    assert _header_functions("awq_aux.h") == sorted(_lib.AUX_EXPORTS)
+    for sym in _lib.EXPORTS + _lib.AUX_EXPORTS:
         assert hasattr(lib, sym), sym
 
 
 def test_shared_object_exports_symbols_with_c_linkage():
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     names = {line.split()[-1] for line in out.splitlines() if line.strip()}
-    for sym in _lib.EXPORTS:
+    for sym in _lib.EXPORTS + _lib.AUX_EXPORTS:
         assert sym in names, f"{sym} not exported unmangled"
 
 
