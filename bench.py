@@ -110,9 +110,15 @@ def main():
     from sglang_awq_amd.distributed import init_tensor_parallel
     from sglang_awq_amd.linear import ColumnParallelLinear, RowParallelLinear
 
-    dev = torch.device("cuda", local_rank)
+    # BENCH_TEST_BACKEND=gloo + BENCH_TEST_ONE_DEVICE=1: rehearsal of the N > 1 code path on a one-GPU box (every
+    # rank on device 0, collectives over gloo, no graph capture).  Never used for reported numbers.
+    test_backend = os.environ.get("BENCH_TEST_BACKEND")
+    dev = torch.device("cuda", 0 if os.environ.get("BENCH_TEST_ONE_DEVICE") else local_rank)
     torch.cuda.set_device(dev)
-    tp = init_tensor_parallel(backend="nccl", device=dev) if world > 1 else init_tensor_parallel()
+    if world > 1:
+        tp = init_tensor_parallel(backend=test_backend or "nccl", device=None if test_backend else dev)
+    else:
+        tp = init_tensor_parallel()
     M = args.m
     cfg = AWQConfig(weight_bits=4, group_size=GROUP, zero_point=True)
 
@@ -160,7 +166,7 @@ def main():
         r(x_row)                      # includes the all-reduce when tp > 1
 
     # ---- graphs of `sets` steps (one pass over every weight set) + a remainder graph ------------
-    use_graph = not args.no_graph
+    use_graph = not args.no_graph and not test_backend
     graphs = {}
 
     def capture(n):
