@@ -110,8 +110,10 @@ int awq_gemm_ex(const void* x, int64_t ldx, const int32_t* qweight, const void* 
  * AWQMarlinLinearMethod.process_weights_after_loading); its plain AWQ method keeps the checkpoint layout
  * (awq.py:429-432).  awq_repack writes an MFMA-fragment-major copy of (qweight, qzeros, scales) into
  * `packed` (awq_repacked_bytes() bytes, 16-byte aligned); awq_gemm_repacked then computes the same result as
- * awq_gemm for M <= 32 — same per-element rounding, fp32 accumulation, bias epilogue — from that copy, with
- * linear weight streaming and no cross-workgroup reduction (no workspace).
+ * awq_gemm — same per-element rounding, fp32 accumulation, bias epilogue — from that copy: for M <= 32 a
+ * streaming GEMV (linear weight stream, no cross-workgroup reduction, no workspace), for larger M an MFMA-bound
+ * tiled kernel whose B fragments go from the copy straight to registers (an M <= 32 call whose reduction scratch
+ * would not fit returns AWQ_ERR_BAD_VARIANT: use awq_gemm).
  * Supported: fp16, K % 128 == 0, group_size % 128 == 0; otherwise awq_repacked_bytes returns 0 and the other
  * two return AWQ_ERR_BAD_VARIANT (callers keep using awq_gemm).
  */

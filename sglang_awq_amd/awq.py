@@ -86,8 +86,8 @@ class AWQConfig(QuantizationConfig):
 class AWQLinearMethod(LinearMethodBase):
     """Linear method for AWQ (awq.py:352-451)."""
 
-    # decode batches at or below this go to the repacked-layout kernel when a repacked copy exists
-    REPACKED_MAX_M = 32
+    # with a repacked copy every batch size runs on it (GEMV passes up to 160 rows, MFMA-tiled kernel beyond)
+    REPACKED_MAX_M = 1 << 30
 
     def __init__(self, quant_config: AWQConfig, apply_mode: Optional[str] = None, repack: Optional[bool] = None):
         self.quant_config = quant_config

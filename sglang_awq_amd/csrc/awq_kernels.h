@@ -47,5 +47,6 @@ bool repacked_supported(int64_t K, int64_t N, int64_t g, int dtype);
 int launch_repack(const int32_t* qweight, const void* scales, const int32_t* qzeros, void* packed, int64_t K, int64_t N, int64_t g,
                   int dtype, hipStream_t stream);
 int launch_gemv_repacked(const GemmArgs& a, const void* packed);
+int launch_gemm_repacked_tiled(const GemmArgs& a, const void* packed);   // any M, MFMA-bound prefill shapes
 
 }  // namespace awq

@@ -220,6 +220,137 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
   }
 }
 
+// ------------------------------------------------------------------------------------------ prefill GEMM
+// Large M on the repacked layout.  The B operand never touches LDS: every wave streams the fragment-major
+// dwords of its own 64 columns straight into registers, dequantises each dword into one MFMA B fragment
+// (13 VALU ops, no transposes) and reuses it for 8 row tiles, so per fragment 8 MFMAs (128 cycles of matrix
+// pipe) cover ~60 cycles of VALU issue.  Only x goes through LDS: 256 x 128 halves per K step, double-buffered,
+// 16-byte chunks XOR-swizzled so the 16 rows of a fragment read hit 16 different bank groups; one barrier per
+// K step.  Workgroup = 4 waves (2 x 2), tile 256 x 128, wave tile 128 x 64 = 8 x 4 MFMA 16x16x32 tiles
+// (128 accumulator registers); one workgroup per CU (128 KiB LDS), XCD-aware tile order.
+// (Pinning a dequantise / MFMA interleave with sched_group_barrier was measured SLOWER, 561 vs 663 TFLOP/s:
+// hipcc's own schedule is kept.)
+constexpr int kPfBM = 256, kPfBN = 128;
+
+__device__ __forceinline__ int pf_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }   // [rows][128 halves]
+
+__global__ __launch_bounds__(256, 1) void gemm_repacked_tiled_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+                                                                      const u32x4_t* __restrict__ qw_r, const uint32_t* __restrict__ zs_r,
+                                                                      const void* __restrict__ bias, void* __restrict__ y, int M, int K,
+                                                                      int N, int g, int NG, int nbx, int nby) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char As[];      // 2 x 64 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int q = lane >> 4, r = lane & 15;
+  const int KB = K / 128, groups = K / g;
+
+  const int nwg = nbx * nby, bid = blockIdx.x;
+  const int xcd = bid & 7, qd = nwg >> 3, rem = nwg & 7;
+  const int logical = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (bid >> 3);
+  const int bm = (logical / nbx) * kPfBM;
+  const int bn = (logical % nbx) * kPfBN;
+
+  int cg[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = (bn + wn * 64) / 16 + j;
+    cg[j] = c < NG ? c : NG - 1;                       // clamped: columns >= N are never stored
+  }
+
+  u32x4_t a_st[16];          // next x tile: 256 rows x 16 chunks / 256 threads
+  u32x4_t w_cur[4], w_nxt[4];
+  uint32_t zs_cur[4], zs_nxt[4];
+
+  auto load_a = [&](int kb) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c >> 4, chunk = c & 15;
+      const int m = bm + row < M ? bm + row : M - 1;
+      a_st[i] = *(const u32x4_t*)(x + (size_t)m * ldx + kb * 128 + chunk * 8);
+    }
+  };
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = tid + 256 * i;
+      *(u32x4_t*)(As + buf * 65536 + pf_off(c >> 4, c & 15)) = a_st[i];
+    }
+  };
+  auto load_b = [&](u32x4_t (&w)[4], uint32_t (&zs)[4], int kb) {
+    const int grp = (kb * 128) / g;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w[j] = qw_r[((size_t)cg[j] * KB + kb) * 64 + lane];
+      zs[j] = zs_r[((size_t)cg[j] * groups + grp) * 16 + r];
+    }
+  };
+
+  float4_t acc[8][4];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[mi][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+  load_a(0);
+  load_b(w_cur, zs_cur, 0);
+  store_a(0);
+  __syncthreads();
+
+  const half2_t c960 = {(half_t)960.f, (half_t)960.f};
+  for (int kb = 0; kb < KB; ++kb) {
+    const int nxt = kb + 1 < KB ? kb + 1 : kb;         // clamped, unconditional prefetch (no branch between load and use)
+    load_a(nxt);
+    load_b(w_nxt, zs_nxt, nxt);
+    const unsigned char* Ab = As + (kb & 1) * 65536;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      u32x4_t af[8];
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) af[mi] = *(const u32x4_t*)(Ab + pf_off(wm * 128 + mi * 16 + r, d * 4 + q));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const half2_t s2 = as_h2(pack_lo16(zs_cur[j], zs_cur[j]));
+        const half2_t z1024 = as_h2(pack_hi16(zs_cur[j], zs_cur[j]));
+        const u32x4_t frag = rp_dequant(w_cur[j][d], z1024, z1024 - c960, s2);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+          acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, af[mi]), __builtin_bit_cast(half8_t, frag), acc[mi][j], 0, 0, 0);
+      }
+    }
+    store_a((kb + 1) & 1);                             // the other buffer: nobody reads it until the barrier below
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { w_cur[j] = w_nxt[j]; zs_cur[j] = zs_nxt[j]; }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = bm + wm * 128 + mi * 16 + 4 * q + i;
+      if (m < M) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = bn + wn * 64 + j * 16 + r;
+          if (n < N) store_output<AWQ_DTYPE_F16>(y, (size_t)m * N + n, acc[mi][j][i], bias, n);
+        }
+      }
+    }
+}
+
+int launch_gemm_repacked_tiled(const GemmArgs& a, const void* packed) {
+  if (!repacked_supported(a.K, a.N, a.g, a.dtype) || a.M < 1 || a.ldx % 8 || (((uintptr_t)a.x) & 15)) return AWQ_ERR_BAD_VARIANT;
+  const int NG = (a.N + 15) / 16;
+  const int nbx = (a.N + kPfBN - 1) / kPfBN, nby = (a.M + kPfBM - 1) / kPfBM;
+  const u32x4_t* qw_r = (const u32x4_t*)packed;
+  const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
+  (void)hipFuncSetAttribute((const void*)gemm_repacked_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  hipLaunchKernelGGL(gemm_repacked_tiled_kernel, dim3(nbx * nby), dim3(256), 131072, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r, a.bias,
+                     a.y, a.M, a.K, a.N, a.g, NG, nbx, nby);
+  return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
+
 // ------------------------------------------------------------------------------------------ host
 static inline int rp_groups(int N) { return (N + 15) / 16; }
 

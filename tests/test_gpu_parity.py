@@ -174,6 +174,29 @@ def test_gemm_repacked_vs_oracle(ops, M):
     assert ops.awq_repack(*_dev(*synth.make_awq_weights(256, 64, 128, "bf16", "A", 1))) is None      # bf16: not supported
 
 
+def test_gemm_repacked_tiled_vs_oracle(ops):
+    """M > 32 on the repacked copy: the register-direct-B tiled kernel; ragged M / N against its 256 x 128 tile."""
+    for (M, K, N, g) in [(33, 128, 128, 128), (64, 256, 136, 128), (100, 512, 1056, 128), (256, 1024, 256, 1024),
+                         (257, 384, 264, 128), (300, 256, 2304, 128), (1024, 128, 64, 128)]:
+        qw, s, qz = synth.make_awq_weights(K, N, g, "f16", "A", seed=M * 3 + K + N)
+        x = synth.make_activations(M, K, "f16", "A", seed=M + K + 1)
+        packed = ops.awq_repack(*_dev(qw, s, qz))
+        y = to_np(ops.awq_gemm_repacked(to_torch(x, DEV), packed, K, N, g))
+        _, exact = c_oracle.gemm(x, qw, s, qz, want_exact=True)
+        assert_gemm_close(y, exact, "f16", what=f"repacked tiled M={M} K={K} N={N} g={g}")
+
+
+def test_gemm_repacked_tiled_prefill_shape_one_hot(ops):
+    K, N, g, M = 4096, 11008, 128, 2048
+    dq, ds, dz = _dev(*synth.make_awq_weights(K, N, g, "f16", "A", 779))
+    W = ops.awq_dequantize(dq, ds, dz)
+    packed = ops.awq_repack(dq, ds, dz)
+    x = torch.zeros(M, K, dtype=torch.float16, device=DEV)
+    ks = (torch.arange(M, device=DEV) * 7 + 3) % K
+    x[torch.arange(M, device=DEV), ks] = 1.0
+    assert torch.equal(ops.awq_gemm_repacked(x, packed, K, N, g), W[ks])
+
+
 def test_gemm_repacked_one_hot_rows_bit_exact_full_shape(ops):
     K, N, g = 4096, 11008, 128
     qw, s, qz = _dev(*synth.make_awq_weights(K, N, g, "f16", "F", 4243))
