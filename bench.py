@@ -268,11 +268,12 @@ def main():
     value = world * bytes_step * args.steps / wall / 1e9
     flops_step = launches_per_step * 2 * M * K_DIM * N_DIM
     out = {
-        "metric": "AWQ int4 GEMM GB/s (algorithmic bytes: packed weight + x + y) at the decode shape",
+        "metric": "AWQ int4 GEMM GB/s (algorithmic bytes: packed weight + x + y) at the decode shape" if M <= 64 else
+                  "AWQ int4 GEMM at the prefill shape (see roofline for TFLOP/s)",
         "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(wall / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"awq_gemm M={M} K={K_DIM} N={N_DIM} g={GROUP} fp16 (BASELINE configs[1]); step = column-parallel + "
+        "config": {"workload": f"awq_gemm M={M} K={K_DIM} N={N_DIM} g={GROUP} fp16 (BASELINE configs[{1 if M <= 64 else 2}]); step = column-parallel + "
                                f"row-parallel AWQ linear per rank" + (" + RCCL all-reduce [M,11008] fp16" if world > 1 else ""),
                    "weight_sets": sets, "graph_replay": use_graph, "parallelism": f"tp{world}",
                    "tflops": round(world * flops_step * args.steps / wall / 1e12, 3),

@@ -136,8 +136,11 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
                                                                           const u32x4_t* __restrict__ qw_r,
                                                                           const uint32_t* __restrict__ zs_r,
                                                                           const void* __restrict__ bias, void* __restrict__ y,
-                                                                          int M, int K, int N, int g, int NG, int per_wave) {
+                                                                          int M, int K, int N, int g, int NG, int per_wave,
+                                                                          unsigned long long* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) float red[];    // [W][M][16 G]
+#define RP_STAMP(slot) do { if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  RP_STAMP(0);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, r = lane & 15;
@@ -166,6 +169,7 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
       rp_load<G, NT, MT>(buf[t], qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
     }
     __builtin_amdgcn_sched_barrier(0);
+    RP_STAMP(1);
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       if (kb_begin + t >= KB) {
@@ -176,6 +180,7 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
       }
       rp_compute<G, MT>(buf[t], acc);
       __builtin_amdgcn_sched_barrier(0);
+      if (t == 0) RP_STAMP(2);
     }
   } else {
     // steady state has no branch between a load and its use (exact counted waits); only the prologue and the
@@ -197,7 +202,8 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
     if (kb + 2 < kb_end) rp_compute<G, MT>(A, acc);
   }
 
-  // D[m = 4q + i][n = r] per column group -> LDS, summed over the 8 waves in fixed order
+  RP_STAMP(3);
+  // D[m = 4q + i][n = r] per column group -> LDS, summed over the waves in fixed order
   const int SW = 16 * G;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -209,6 +215,7 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
         if (m < M) red[((size_t)wave * M + m) * SW + c * 16 + r] = acc[mt][c][i];
       }
   __syncthreads();
+  RP_STAMP(4);
   for (int idx = threadIdx.x; idx < M * SW; idx += W * 64) {
     const int m = idx / SW, col = idx - m * SW;
     const int n = cg0 * 16 + col;
@@ -230,25 +237,31 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
 // (128 accumulator registers); one workgroup per CU (128 KiB LDS), XCD-aware tile order.
 // (Pinning a dequantise / MFMA interleave with sched_group_barrier was measured SLOWER, 561 vs 663 TFLOP/s:
 // hipcc's own schedule is kept.)
-constexpr int kPfBM = 256, kPfBN = 128;
 
 __device__ __forceinline__ int pf_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }   // [rows][128 halves]
 
-__global__ __launch_bounds__(256, 1) void gemm_repacked_tiled_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+// <WM, WN> waves along M / N; wave tile = (16 MI) x 64 with MI = 8 (4 waves) or 4 (8 waves); workgroup tile BMt x BNt:
+//   <2,2> 256 x 128 (4 waves)   <4,2> 256 x 128 (8 waves, 2 per SIMD)   <1,4> 128 x 256 (4 waves, half the x traffic per CU)
+template <int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void gemm_repacked_tiled_kernel(const uint16_t* __restrict__ x, int64_t ldx,
                                                                       const u32x4_t* __restrict__ qw_r, const uint32_t* __restrict__ zs_r,
                                                                       const void* __restrict__ bias, void* __restrict__ y, int M, int K,
                                                                       int N, int g, int NG, int nbx, int nby) {
   extern __shared__ __attribute__((aligned(16))) unsigned char As[];      // 2 x 64 KiB
+  constexpr int MI = WM * WN == 8 ? 4 : 8;         // 16 x 16 row tiles per wave
+  constexpr int BMt = WM * MI * 16, BNt = WN * 64;
+  constexpr int NT_ = WM * WN * 64;                // threads
+  constexpr int AL = BMt * 16 / NT_;               // x-tile chunks (16 B) per thread
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int q = lane >> 4, r = lane & 15;
   const int KB = K / 128, groups = K / g;
 
   const int nwg = nbx * nby, bid = blockIdx.x;
   const int xcd = bid & 7, qd = nwg >> 3, rem = nwg & 7;
   const int logical = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (bid >> 3);
-  const int bm = (logical / nbx) * kPfBM;
-  const int bn = (logical % nbx) * kPfBN;
+  const int bm = (logical / nbx) * BMt;
+  const int bn = (logical % nbx) * BNt;
 
   int cg[4];
 #pragma unroll
@@ -257,14 +270,14 @@ __global__ __launch_bounds__(256, 1) void gemm_repacked_tiled_kernel(const uint1
     cg[j] = c < NG ? c : NG - 1;                       // clamped: columns >= N are never stored
   }
 
-  u32x4_t a_st[16];          // next x tile: 256 rows x 16 chunks / 256 threads
+  u32x4_t a_st[AL];          // next x tile: 256 rows x 16 chunks / threads
   u32x4_t w_cur[4], w_nxt[4];
   uint32_t zs_cur[4], zs_nxt[4];
 
   auto load_a = [&](int kb) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int c = tid + 256 * i;
+    for (int i = 0; i < AL; ++i) {
+      const int c = tid + NT_ * i;
       const int row = c >> 4, chunk = c & 15;
       const int m = bm + row < M ? bm + row : M - 1;
       a_st[i] = *(const u32x4_t*)(x + (size_t)m * ldx + kb * 128 + chunk * 8);
@@ -272,9 +285,9 @@ __global__ __launch_bounds__(256, 1) void gemm_repacked_tiled_kernel(const uint1
   };
   auto store_a = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int c = tid + 256 * i;
-      *(u32x4_t*)(As + buf * 65536 + pf_off(c >> 4, c & 15)) = a_st[i];
+    for (int i = 0; i < AL; ++i) {
+      const int c = tid + NT_ * i;
+      *(u32x4_t*)(As + buf * (BMt * 256) + pf_off(c >> 4, c & 15)) = a_st[i];
     }
   };
   auto load_b = [&](u32x4_t (&w)[4], uint32_t (&zs)[4], int kb) {
@@ -286,9 +299,9 @@ __global__ __launch_bounds__(256, 1) void gemm_repacked_tiled_kernel(const uint1
     }
   };
 
-  float4_t acc[8][4];
+  float4_t acc[MI][4];
 #pragma unroll
-  for (int mi = 0; mi < 8; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[mi][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
@@ -302,19 +315,19 @@ __global__ __launch_bounds__(256, 1) void gemm_repacked_tiled_kernel(const uint1
     const int nxt = kb + 1 < KB ? kb + 1 : kb;         // clamped, unconditional prefetch (no branch between load and use)
     load_a(nxt);
     load_b(w_nxt, zs_nxt, nxt);
-    const unsigned char* Ab = As + (kb & 1) * 65536;
+    const unsigned char* Ab = As + (kb & 1) * (BMt * 256);
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      u32x4_t af[8];
+      u32x4_t af[MI];
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi) af[mi] = *(const u32x4_t*)(Ab + pf_off(wm * 128 + mi * 16 + r, d * 4 + q));
+      for (int mi = 0; mi < MI; ++mi) af[mi] = *(const u32x4_t*)(Ab + pf_off(wm * (MI * 16) + mi * 16 + r, d * 4 + q));
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const half2_t s2 = as_h2(pack_lo16(zs_cur[j], zs_cur[j]));
         const half2_t z1024 = as_h2(pack_hi16(zs_cur[j], zs_cur[j]));
         const u32x4_t frag = rp_dequant(w_cur[j][d], z1024, z1024 - c960, s2);
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
           acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, af[mi]), __builtin_bit_cast(half8_t, frag), acc[mi][j], 0, 0, 0);
       }
     }
@@ -325,10 +338,10 @@ __global__ __launch_bounds__(256, 1) void gemm_repacked_tiled_kernel(const uint1
   }
 
 #pragma unroll
-  for (int mi = 0; mi < 8; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = bm + wm * 128 + mi * 16 + 4 * q + i;
+      const int m = bm + wm * (MI * 16) + mi * 16 + 4 * q + i;
       if (m < M) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -339,15 +352,26 @@ __global__ __launch_bounds__(256, 1) void gemm_repacked_tiled_kernel(const uint1
     }
 }
 
+template <int WM, int WN>
+static void pf_launch(const GemmArgs& a, const u32x4_t* qw_r, const uint32_t* zs_r, int NG) {
+  constexpr int MI = WM * WN == 8 ? 4 : 8;
+  constexpr int BMt = WM * MI * 16, BNt = WN * 64;
+  const int nbx = (a.N + BNt - 1) / BNt, nby = (a.M + BMt - 1) / BMt;
+  const size_t lds = 2 * BMt * 256;
+  (void)hipFuncSetAttribute((const void*)gemm_repacked_tiled_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((gemm_repacked_tiled_kernel<WM, WN>), dim3(nbx * nby), dim3(WM * WN * 64), lds, a.stream, (const uint16_t*)a.x, a.ldx,
+                     qw_r, zs_r, a.bias, a.y, a.M, a.K, a.N, a.g, NG, nbx, nby);
+}
+
 int launch_gemm_repacked_tiled(const GemmArgs& a, const void* packed) {
   if (!repacked_supported(a.K, a.N, a.g, a.dtype) || a.M < 1 || a.ldx % 8 || (((uintptr_t)a.x) & 15)) return AWQ_ERR_BAD_VARIANT;
   const int NG = (a.N + 15) / 16;
-  const int nbx = (a.N + kPfBN - 1) / kPfBN, nby = (a.M + kPfBM - 1) / kPfBM;
   const u32x4_t* qw_r = (const u32x4_t*)packed;
   const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
-  (void)hipFuncSetAttribute((const void*)gemm_repacked_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-  hipLaunchKernelGGL(gemm_repacked_tiled_kernel, dim3(nbx * nby), dim3(256), 131072, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r, a.bias,
-                     a.y, a.M, a.K, a.N, a.g, NG, nbx, nby);
+  static const int env_shape = getenv("AWQ_PF_SHAPE") ? atoi(getenv("AWQ_PF_SHAPE")) : 14;      // A/B knob: 22, 42, 14
+  if (env_shape == 22) pf_launch<2, 2>(a, qw_r, zs_r, NG);
+  else if (env_shape == 42) pf_launch<4, 2>(a, qw_r, zs_r, NG);
+  else pf_launch<1, 4>(a, qw_r, zs_r, NG);
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
@@ -377,6 +401,10 @@ int launch_repack(const int32_t* qweight, const void* scales, const int32_t* qze
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
+// diagnostic only (tools/kbench rstamps): when set, workgroups write 100 MHz-clock stamps into this device buffer
+static unsigned long long* g_rp_stamp_buffer = nullptr;
+extern "C" void awq_debug_set_stamp_buffer(void* p) { g_rp_stamp_buffer = (unsigned long long*)p; }
+
 template <int G, int W, bool NT, int MT>
 static void rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wave, int nwg, size_t lds) {
   const u32x4_t* qw_r = (const u32x4_t*)packed;
@@ -384,7 +412,7 @@ static void rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wav
   dim3 grid(nwg), block(W * 64);
 #define RP_GO(TT)                                                                                                                 \
   hipLaunchKernelGGL((gemv_repacked_kernel<G, TT, W, NT, MT>), grid, block, lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r, a.bias, \
-                     a.y, a.M, a.K, a.N, a.g, NG, per_wave)
+                     a.y, a.M, a.K, a.N, a.g, NG, per_wave, g_rp_stamp_buffer)
   if constexpr (MT == 1) {
     switch (per_wave) {
       case 1: RP_GO(1); break;

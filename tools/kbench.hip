@@ -350,6 +350,50 @@ static int cmd_rgemm(int argc, char** argv) {
   return 0;
 }
 
+extern "C" void awq_debug_set_stamp_buffer(void* p);   // diagnostic hook of libawq_hip.so (not in the public header)
+
+static int cmd_rstamps(int argc, char** argv) {
+  if (argc < 6) { fprintf(stderr, "usage: kbench rstamps M K N g [sets]\n"); return 2; }
+  const int M = atoi(argv[2]), K = atoi(argv[3]), N = atoi(argv[4]), g = atoi(argv[5]);
+  const int sets = argc > 6 ? atoi(argv[6]) : 16;
+  const size_t pbytes = awq_repacked_bytes(K, N, g, AWQ_DTYPE_F16);
+  hipStream_t st; CK(hipStreamCreate(&st));
+  std::vector<void*> packed(sets);
+  auto w = make_weights(1, K, N, g, AWQ_DTYPE_F16);
+  for (int i = 0; i < sets; ++i) {
+    CK(hipMalloc(&packed[i], pbytes));
+    fill_u32(w[0].qw, (size_t)K * N / 8);
+    if (awq_repack(w[0].qw, w[0].sc, w[0].qz, packed[i], K, N, g, AWQ_DTYPE_F16, st)) return 1;
+    CK(hipStreamSynchronize(st));
+  }
+  void *x, *y; unsigned long long* dbg;
+  CK(hipMalloc(&x, (size_t)M * K * 2)); fill_scales(x, (size_t)M * K, AWQ_DTYPE_F16, -1.f, 1.f);
+  CK(hipMalloc(&y, (size_t)M * N * 2));
+  const int max_wg = 4096;
+  CK(hipMalloc(&dbg, (size_t)max_wg * 64));
+  awq_debug_set_stamp_buffer(dbg);
+  std::vector<unsigned long long> h((size_t)max_wg * 8);
+  for (int rep = 0; rep < 2 * sets + 3; ++rep) {
+    CK(hipMemsetAsync(dbg, 0, (size_t)max_wg * 64, st));
+    if (awq_gemm_repacked(x, K, packed[rep % sets], nullptr, y, M, K, N, g, AWQ_DTYPE_F16, st)) return 1;
+    CK(hipStreamSynchronize(st));
+  }
+  awq_debug_set_stamp_buffer(nullptr);
+  CK(hipMemcpy(h.data(), dbg, (size_t)max_wg * 64, hipMemcpyDeviceToHost));
+  unsigned long long t0 = ~0ull; int nwg = 0;
+  for (int b = 0; b < max_wg; ++b) if (h[(size_t)b * 8]) { nwg = b + 1; if (h[(size_t)b * 8] < t0) t0 = h[(size_t)b * 8]; }
+  const char* names[6] = {"start", "loads issued", "first k-block computed", "all k-blocks computed", "after barrier", "y stored"};
+  printf("rstamps (wave 0 of each workgroup): %d workgroups, us after the first workgroup started\n", nwg);
+  for (int slot = 0; slot < 6; ++slot) {
+    std::vector<double> v;
+    for (int b = 0; b < nwg; ++b) if (h[(size_t)b * 8 + slot]) v.push_back((double)(h[(size_t)b * 8 + slot] - t0) * 0.01);
+    if (v.empty()) continue;
+    std::sort(v.begin(), v.end());
+    printf("  %-24s n=%4zu  min %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f\n", names[slot], v.size(), v.front(), v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+  }
+  return 0;
+}
+
 static int cmd_dequant(int argc, char** argv) {
   if (argc < 6) { fprintf(stderr, "usage: kbench dequant K N g dtype [sets] [iters]\n"); return 2; }
   const int K = atoi(argv[2]), N = atoi(argv[3]), g = atoi(argv[4]), dtype = atoi(argv[5]);
@@ -385,6 +429,7 @@ int main(int argc, char** argv) {
   if (cmd == "dequant") return cmd_dequant(argc, argv);
   if (cmd == "stamps") return cmd_stamps(argc, argv);
   if (cmd == "rgemm") return cmd_rgemm(argc, argv);
+  if (cmd == "rstamps") return cmd_rstamps(argc, argv);
   if (cmd == "read") return cmd_read(argc, argv);
   fprintf(stderr, "unknown command %s\n", argv[1]);
   return 2;
