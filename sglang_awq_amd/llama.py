@@ -174,7 +174,8 @@ class LlamaForCausalLM(torch.nn.Module):
             from . import aux_ops
 
             h = self.embed_tokens[tokens]                       # residual stream, updated in place by add_rmsnorm
-            mask = (self.arange_seq.view(1, 1, 1, -1) <= pos.view(-1, 1, 1, 1))
+            # additive mask built ONCE per step (a boolean mask is re-converted inside SDPA in every layer)
+            mask = torch.where(self.arange_seq.view(1, 1, 1, -1) <= pos.view(-1, 1, 1, 1), 0.0, float("-inf")).to(self.dtype)
             delta = None
             for layer in self.layers:
                 delta = layer.forward_fused(h, delta, pos, self.cos_table, self.sin_table, mask)
