@@ -405,68 +405,98 @@ int launch_repack(const int32_t* qweight, const void* scales, const int32_t* qze
 static unsigned long long* g_rp_stamp_buffer = nullptr;
 extern "C" void awq_debug_set_stamp_buffer(void* p) { g_rp_stamp_buffer = (unsigned long long*)p; }
 
+// Which (waves, row tiles, strip width G, straight-line depth T) instantiations fit their register budget
+// (128 VGPRs at 16 waves, 256 at 8) without scratch — from hipcc's -Rpass-analysis=kernel-resource-usage
+// (tools/rp_resources.py prints the table).  A spilling variant is never built nor chosen: G = 3, T = 4 at
+// 16 waves spills 52 B / lane and ran 8192 x 10240 at 18.1 us instead of 13.0.
+constexpr bool rp_fits(int W, int MT, int G, int T) {
+  if (MT == 2) return T == 0 || (T == 4 && G <= 5);
+  if (W == 16) return G <= (T == 0 ? 5 : T <= 2 ? 8 : T == 3 ? 4 : T == 4 ? 2 : T == 5 ? 1 : 0);
+  return G <= (T <= 4 ? 8 : T == 5 ? 6 : 4);
+}
+
 template <int G, int W, bool NT, int MT>
-static void rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wave, int nwg, size_t lds) {
+static void rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wave, int T, int nwg, size_t lds) {
   const u32x4_t* qw_r = (const u32x4_t*)packed;
   const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
   dim3 grid(nwg), block(W * 64);
-#define RP_GO(TT)                                                                                                                 \
-  hipLaunchKernelGGL((gemv_repacked_kernel<G, TT, W, NT, MT>), grid, block, lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r, a.bias, \
-                     a.y, a.M, a.K, a.N, a.g, NG, per_wave, g_rp_stamp_buffer)
-  if constexpr (MT == 1) {
-    switch (per_wave) {
-      case 1: RP_GO(1); break;
-      case 2: RP_GO(2); break;
-      case 3: RP_GO(3); break;
-      case 4: RP_GO(4); break;
-      case 5: RP_GO(5); break;
-      case 6: RP_GO(6); break;
-      default: RP_GO(0); break;
-    }
-  } else {                       // two row tiles: fewer specialisations (registers, build time)
-    if (per_wave == 4) RP_GO(4); else RP_GO(0);
+#define RP_GO(TT)                                                                                                                  \
+  if constexpr (rp_fits(W, MT, G, TT) && (MT == 1 || TT == 0 || TT == 4))                                                            \
+    hipLaunchKernelGGL((gemv_repacked_kernel<G, TT, W, NT, MT>), grid, block, lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r, \
+                       a.bias, a.y, a.M, a.K, a.N, a.g, NG, per_wave, g_rp_stamp_buffer)
+  switch (T) {
+    case 1: RP_GO(1); break;
+    case 2: RP_GO(2); break;
+    case 3: RP_GO(3); break;
+    case 4: RP_GO(4); break;
+    case 5: RP_GO(5); break;
+    case 6: RP_GO(6); break;
+    default: RP_GO(0); break;
   }
 #undef RP_GO
 }
 
 template <int W, bool NT, int MT>
-static void rp_launch_g(int G, const GemmArgs& a, const void* packed, int NG, int per_wave, int nwg, size_t lds) {
+static void rp_launch_g(int G, const GemmArgs& a, const void* packed, int NG, int per_wave, int T, int nwg, size_t lds) {
   switch (G) {
-    case 1: rp_launch<1, W, NT, MT>(a, packed, NG, per_wave, nwg, lds); break;
-    case 2: rp_launch<2, W, NT, MT>(a, packed, NG, per_wave, nwg, lds); break;
-    case 3: rp_launch<3, W, NT, MT>(a, packed, NG, per_wave, nwg, lds); break;
-    case 4: rp_launch<4, W, NT, MT>(a, packed, NG, per_wave, nwg, lds); break;
-    case 5: rp_launch<5, W, NT, MT>(a, packed, NG, per_wave, nwg, lds); break;
-    case 6: rp_launch<6, W, NT, MT>(a, packed, NG, per_wave, nwg, lds); break;
-    case 7: rp_launch<7, W, NT, MT>(a, packed, NG, per_wave, nwg, lds); break;
-    default: rp_launch<8, W, NT, MT>(a, packed, NG, per_wave, nwg, lds); break;
+    case 1: rp_launch<1, W, NT, MT>(a, packed, NG, per_wave, T, nwg, lds); break;
+    case 2: rp_launch<2, W, NT, MT>(a, packed, NG, per_wave, T, nwg, lds); break;
+    case 3: rp_launch<3, W, NT, MT>(a, packed, NG, per_wave, T, nwg, lds); break;
+    case 4: rp_launch<4, W, NT, MT>(a, packed, NG, per_wave, T, nwg, lds); break;
+    case 5: rp_launch<5, W, NT, MT>(a, packed, NG, per_wave, T, nwg, lds); break;
+    case 6: rp_launch<6, W, NT, MT>(a, packed, NG, per_wave, T, nwg, lds); break;
+    case 7: rp_launch<7, W, NT, MT>(a, packed, NG, per_wave, T, nwg, lds); break;
+    default: rp_launch<8, W, NT, MT>(a, packed, NG, per_wave, T, nwg, lds); break;
   }
 }
 
+static int rp_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+
 int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
   if (!repacked_supported(a.K, a.N, a.g, a.dtype) || a.M < 1 || a.M > 16 * kRpMaxMT || a.ldx % 8 || (((uintptr_t)a.x) & 15)) return AWQ_ERR_BAD_VARIANT;
-  const int NG = rp_groups(a.N);
-  int G = (NG + 255) / 256;                            // one strip per CU
-  if (G > kRpMaxG) G = kRpMaxG;
+  const int NG = rp_groups(a.N), KB = a.K / 128;
+  const bool two_tiles = a.M > 16;
+  const int MT = two_tiles ? 2 : 1;
+  // A/B knobs for tools/kbench (0 / -1 = heuristic)
+  static const int env_waves = rp_env("AWQ_RP_WAVES", 0), env_nt = rp_env("AWQ_RP_NT", -1), env_g = rp_env("AWQ_RP_G", 0),
+                   env_t = rp_env("AWQ_RP_T", -1);
+  // Strip width: one strip per CU while that needs <= 8 column groups; wider matrices (N > 32768) run several
+  // rounds of 3-group strips on 8-wave workgroups, two of which are resident per CU so one's drain overlaps
+  // the other's stream (145 -> 51 us at 8192 x 57344, 4.8 TB/s).
+  int G = (NG + 255) / 256;
+  bool rounds = false;
+  if (G > kRpMaxG) { G = 3; rounds = true; }                       // measured 51 (G = 3) / 53 (2) / 54.5 (4) / 60 (1) us
+  if (two_tiles && G > 4) { G = 4; rounds = true; }                 // 32 rows: reduction scratch 8 x 32 x 64 floats = 64 KiB at most
+  if (env_g >= 1 && env_g <= kRpMaxG) { G = env_g; rounds = (NG + G - 1) / G > 256; }
   if (G > NG) G = NG;
   const int nwg = (NG + G - 1) / G;
-  const int KB = a.K / 128;
   // 16 waves + non-temporal weight loads for matrices that are streamed from HBM (measured 7.2 vs 8.3 us at
   // 4096 x 11008); small ones (< 12 MB packed, largely L2 / Infinity-Cache resident) run better with 8 waves and
-  // default-policy loads (4.2 vs 4.7 us at 4096 x 4096).  AWQ_RP_WAVES / AWQ_RP_NT override for A/B runs.
+  // default-policy loads (4.2 vs 4.7 us at 4096 x 4096).
   const bool big = (size_t)a.K * a.N / 2 >= (12u << 20);
-  static const int env_waves = getenv("AWQ_RP_WAVES") ? atoi(getenv("AWQ_RP_WAVES")) : 0;
-  static const int env_nt = getenv("AWQ_RP_NT") ? atoi(getenv("AWQ_RP_NT")) : -1;
-  int W = env_waves == 16 || env_waves == 8 ? env_waves : (big ? 16 : 8);
   const bool nt = env_nt >= 0 ? env_nt != 0 : big;
-  const bool two_tiles = a.M > 16;
+  int W = env_waves == 16 || env_waves == 8 ? env_waves : (big && !rounds ? 16 : 8);
   if (two_tiles || (size_t)W * a.M * 16 * G * sizeof(float) > 64 * 1024) W = 8;
+  // depth: every k-block of a wave in flight at once (straight-line, T = per_wave <= 6) when that fits the
+  // register budget, else the double-buffered loop (T = 0); 16 waves fall back to 8 when neither fits
+  auto depth = [&](int w) {
+    const int pw = (KB + w - 1) / w;
+    if (env_t == 0 || rounds) return 0;
+    if (pw <= 6 && rp_fits(w, MT, G, pw) && (MT == 1 || pw == 4)) return pw;
+    return rp_fits(w, MT, G, 0) ? 0 : -1;
+  };
+  int T = depth(W);
+  if (W == 16 && env_waves != 16 && (T < 0 || (T == 0 && (KB + 15) / 16 <= 6))) {   // straight-line did not fit: 8 waves measured better than the 16-wave loop
+    W = 8;
+    T = depth(W);
+  }
+  if (T < 0) return AWQ_ERR_BAD_VARIANT;
   const int per_wave = (KB + W - 1) / W;
   const size_t lds = (size_t)W * a.M * 16 * G * sizeof(float);
   if (lds > 64 * 1024) return AWQ_ERR_BAD_VARIANT;                      // (M = 32 with 8-group strips: callers fall back to awq_gemm)
-  if (two_tiles) rp_launch_g<8, true, 2>(G, a, packed, NG, per_wave, nwg, lds);
-  else if (W == 16) { if (nt) rp_launch_g<16, true, 1>(G, a, packed, NG, per_wave, nwg, lds); else rp_launch_g<16, false, 1>(G, a, packed, NG, per_wave, nwg, lds); }
-  else { if (nt) rp_launch_g<8, true, 1>(G, a, packed, NG, per_wave, nwg, lds); else rp_launch_g<8, false, 1>(G, a, packed, NG, per_wave, nwg, lds); }
+  if (two_tiles) rp_launch_g<8, true, 2>(G, a, packed, NG, per_wave, T, nwg, lds);
+  else if (W == 16) { if (nt) rp_launch_g<16, true, 1>(G, a, packed, NG, per_wave, T, nwg, lds); else rp_launch_g<16, false, 1>(G, a, packed, NG, per_wave, T, nwg, lds); }
+  else { if (nt) rp_launch_g<8, true, 1>(G, a, packed, NG, per_wave, T, nwg, lds); else rp_launch_g<8, false, 1>(G, a, packed, NG, per_wave, T, nwg, lds); }
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 

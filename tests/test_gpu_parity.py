@@ -152,19 +152,15 @@ def test_gemm_skinny_loader_consumer_vs_oracle(ops, dt, M):
 def test_gemm_repacked_vs_oracle(ops, M):
     """MFMA-fragment-major re-layout + its decode kernel: column counts that are not a multiple
     of 16 (padded group), strips of 1..8 column groups, 1..4 k-blocks per wave (straight-line) and more (loop),
-    g = 128 and g = K."""
+    g = 128 and g = K; N > 32768 (and M > 16 with more than 4 groups per CU) runs several rounds of narrow strips."""
     for (K, N, g) in [(128, 16, 128), (256, 72, 128), (512, 1056, 128), (1024, 4096, 128), (4096, 512, 4096),
-                      (4096, 1024, 128), (11008 // 86 * 86, 256, 128), (2048, 11008, 128), (6144, 2048 * 11, 128)]:
+                      (4096, 1024, 128), (11008 // 86 * 86, 256, 128), (2048, 11008, 128), (6144, 2048 * 11, 128),
+                      (256, 32848, 128)]:
         qw, s, qz = synth.make_awq_weights(K, N, g, "f16", "A", seed=M * 13 + K + N)
         x = synth.make_activations(M, K, "f16", "A", seed=M + K)
         b = synth.make_bias(N, "f16", 5)
         packed = ops.awq_repack(*_dev(qw, s, qz))
         assert packed is not None and packed.dtype == torch.uint8
-        strip_groups = -(-((N + 15) // 16) // 256)
-        if M * strip_groups > 128:      # reduction scratch would exceed 64 KiB of LDS: the C side refuses, callers fall back
-            with pytest.raises(_lib.AwqHipError):
-                ops.awq_gemm_repacked(to_torch(x, DEV), packed, K, N, g)
-            continue
         y = to_np(ops.awq_gemm_repacked(to_torch(x, DEV), packed, K, N, g))
         _, exact = c_oracle.gemm(x, qw, s, qz, want_exact=True)
         assert_gemm_close(y, exact, "f16", what=f"repacked M={M} K={K} N={N} g={g}")
