@@ -28,7 +28,7 @@ EXPORTS = (
     "awq_gemm_repacked",
 )
 # include/awq_aux.h (decode-harness helpers, not part of the operator boundary)
-AUX_EXPORTS = ("awq_aux_add_rmsnorm", "awq_aux_rope_kv", "awq_aux_silu_mul")
+AUX_EXPORTS = ("awq_aux_add_rmsnorm", "awq_aux_rope_kv", "awq_aux_decode_attention", "awq_aux_silu_mul")
 ABI_VERSION = 1
 
 DTYPE_F16, DTYPE_BF16, DTYPE_F32 = 0, 1, 2
@@ -79,6 +79,8 @@ def _bind(L):
     L.awq_aux_add_rmsnorm.restype = ci
     L.awq_aux_rope_kv.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp]
     L.awq_aux_rope_kv.restype = ci
+    L.awq_aux_decode_attention.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, ctypes.c_float, vp]
+    L.awq_aux_decode_attention.restype = ci
     L.awq_aux_silu_mul.argtypes = [vp, vp, i64, i64, vp]
     L.awq_aux_silu_mul.restype = ci
 

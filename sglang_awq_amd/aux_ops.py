@@ -37,6 +37,20 @@ def rope_kv(qkv: torch.Tensor, pos: torch.Tensor, cos_table: torch.Tensor, sin_t
     _lib.check(rc, "awq_aux_rope_kv")
 
 
+def decode_attention(qkv: torch.Tensor, pos: torch.Tensor, cos_table: torch.Tensor, sin_table: torch.Tensor, k_cache: torch.Tensor,
+                     v_cache: torch.Tensor, num_heads: int, num_kv_heads: int, head_dim: int) -> torch.Tensor:
+    """RoPE + KV-cache write + one-token attention in one launch; qkv [B, (Hq + 2 Hkv) D] is not modified.
+    Returns [B, Hq * D]."""
+    assert qkv.dtype == torch.float16 and qkv.is_contiguous() and pos.dtype == torch.int64
+    assert k_cache.is_contiguous() and v_cache.is_contiguous() and cos_table.dtype == torch.float32
+    out = torch.empty((qkv.shape[0], num_heads * head_dim), dtype=torch.float16, device=qkv.device)
+    rc = _lib.load().awq_aux_decode_attention(_vp(qkv), _vp(pos), _vp(cos_table), _vp(sin_table), _vp(k_cache), _vp(v_cache), _vp(out),
+                                              qkv.shape[0], num_heads, num_kv_heads, head_dim, k_cache.shape[2],
+                                              float(head_dim) ** -0.5, _stream(qkv))
+    _lib.check(rc, "awq_aux_decode_attention")
+    return out
+
+
 def silu_mul(gate_up: torch.Tensor) -> torch.Tensor:
     assert gate_up.dtype == torch.float16 and gate_up.is_contiguous() and gate_up.dim() == 2
     inter = gate_up.shape[1] // 2

@@ -88,7 +88,7 @@ class LlamaDecoderLayer(torch.nn.Module):
         self.register_buffer("k_cache", torch.zeros(max_batch, self.num_kv_heads, max_seq, self.head_dim, dtype=dtype), persistent=False)
         self.register_buffer("v_cache", torch.zeros(max_batch, self.num_kv_heads, max_seq, self.head_dim, dtype=dtype), persistent=False)
 
-    def forward_fused(self, h, delta, pos, cos_table, sin_table, mask):
+    def forward_fused(self, h, delta, pos, cos_table, sin_table):
         """Same layer with the elementwise neighbours fused (aux_ops): h is the residual stream (updated in place),
         delta the previous layer's MLP output still to be added.  Returns this layer's MLP output (the next delta)."""
         from . import aux_ops
@@ -96,10 +96,8 @@ class LlamaDecoderLayer(torch.nn.Module):
         B = h.shape[0]
         x = aux_ops.add_rmsnorm(h, delta, self.input_layernorm, self.cfg.rms_norm_eps)
         qkv, _ = self.qkv_proj(x)
-        aux_ops.rope_kv(qkv, pos, cos_table, sin_table, self.k_cache, self.v_cache, self.num_heads, self.num_kv_heads, self.head_dim)
-        q = qkv[:, :self.q_size].view(B, self.num_heads, 1, self.head_dim)
-        attn = F.scaled_dot_product_attention(q, self.k_cache[:B], self.v_cache[:B], attn_mask=mask,
-                                              enable_gqa=self.num_heads != self.num_kv_heads)
+        attn = aux_ops.decode_attention(qkv, pos, cos_table, sin_table, self.k_cache, self.v_cache, self.num_heads, self.num_kv_heads,
+                                        self.head_dim)
         o, _ = self.o_proj(attn.reshape(B, self.q_size))
         x = aux_ops.add_rmsnorm(h, o, self.post_attention_layernorm, self.cfg.rms_norm_eps)
         gu, _ = self.gate_up_proj(x)
@@ -174,11 +172,9 @@ class LlamaForCausalLM(torch.nn.Module):
             from . import aux_ops
 
             h = self.embed_tokens[tokens]                       # residual stream, updated in place by add_rmsnorm
-            # additive mask built ONCE per step (a boolean mask is re-converted inside SDPA in every layer)
-            mask = torch.where(self.arange_seq.view(1, 1, 1, -1) <= pos.view(-1, 1, 1, 1), 0.0, float("-inf")).to(self.dtype)
             delta = None
             for layer in self.layers:
-                delta = layer.forward_fused(h, delta, pos, self.cos_table, self.sin_table, mask)
+                delta = layer.forward_fused(h, delta, pos, self.cos_table, self.sin_table)
             h = aux_ops.add_rmsnorm(h, delta, self.norm, self.cfg.rms_norm_eps)
             return torch.matmul(h, self.lm_head.t())
         h = self.embed_tokens[tokens]

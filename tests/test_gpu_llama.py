@@ -108,3 +108,50 @@ def test_tiny_llama_decode_matches_fp32_reference_and_graph_replay():
     # capture itself ran no step (warmup=0); the graph holds exactly one
     seq_graph = [graphed.run(1) for _ in range(5)]
     assert seq_graph == seq_eager
+
+
+@pytest.mark.parametrize("D,Hq,Hkv", [(128, 8, 8), (128, 8, 2), (64, 12, 4)])
+def test_decode_attention_kernel_vs_fp32_reference(D, Hq, Hkv):
+    """awq_aux_decode_attention (RoPE + KV write + one-token attention) against plain fp32 PyTorch: first token
+    (pos 0), ragged positions across the batch, positions beyond one pass of the 4-deep position loop, GQA."""
+    from sglang_awq_amd import aux_ops
+
+    torch.manual_seed(D + Hq)
+    B, S = 5, 300
+    pos = torch.tensor([0, 1, 17, 130, 299], dtype=torch.int64, device=DEV)
+    qkv = torch.randn(B, (Hq + 2 * Hkv) * D, device=DEV).half()
+    kc = (torch.randn(B + 1, Hkv, S, D, device=DEV)).half()        # one more batch slot than used: must stay untouched
+    vc = (torch.randn(B + 1, Hkv, S, D, device=DEV)).half()
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.float32, device=DEV) / D))
+    freqs = torch.outer(torch.arange(S, dtype=torch.float32, device=DEV), inv)
+    cos_t, sin_t = freqs.cos().contiguous(), freqs.sin().contiguous()
+    kc0, vc0, qkv0 = kc.clone(), vc.clone(), qkv.clone()
+
+    out = aux_ops.decode_attention(qkv, pos, cos_t, sin_t, kc, vc, Hq, Hkv, D)
+    torch.cuda.synchronize()
+    assert torch.equal(qkv, qkv0)                                    # input not modified
+
+    def rope(x, c, s):
+        d = D // 2
+        x1, x2 = x[..., :d].float(), x[..., d:].float()
+        return torch.cat([x1 * c - x2 * s, x2 * c + x1 * s], -1).half()
+
+    q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], -1)
+    rep = Hq // Hkv
+    for b in range(B):
+        p = int(pos[b])
+        c, s = cos_t[p], sin_t[p]
+        qb = rope(q[b].view(Hq, D), c, s)
+        kb = rope(k[b].view(Hkv, D), c, s)
+        vb = v[b].view(Hkv, D)
+        assert torch.equal(kc[b, :, p], kb) and torch.equal(vc[b, :, p], vb)            # cache write, bit-exact
+        keep = torch.ones(S, dtype=torch.bool, device=DEV)
+        keep[p] = False
+        assert torch.equal(kc[b][:, keep], kc0[b][:, keep]) and torch.equal(vc[b][:, keep], vc0[b][:, keep])
+        kk = kc[b, :, :p + 1].float().repeat_interleave(rep, 0)
+        vv = vc[b, :, :p + 1].float().repeat_interleave(rep, 0)
+        att = torch.softmax((qb.float().unsqueeze(1) @ kk.transpose(1, 2)) * D ** -0.5, -1)
+        want = (att @ vv).squeeze(1).reshape(-1)
+        err = (out[b].float() - want).abs().max().item()
+        assert err <= 2e-3 + 2e-3 * want.abs().max().item(), f"b={b} pos={p} err={err}"
+    assert torch.equal(kc[B], kc0[B]) and torch.equal(vc[B], vc0[B])
