@@ -58,3 +58,44 @@ def silu_mul(gate_up: torch.Tensor) -> torch.Tensor:
     rc = _lib.load().awq_aux_silu_mul(_vp(gate_up), _vp(act), gate_up.shape[0], inter, _stream(gate_up))
     _lib.check(rc, "awq_aux_silu_mul")
     return act
+
+
+def interleave_gate_up(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor):
+    """Column-permuted copies of a merged gate_up AWQ weight ([K, 2I] logical columns, gate then up) in which the
+    16-column groups alternate gate / up — the order awq_aux_gemv_repacked_fused(silu_mul=1) expects of the tensors
+    its `packed` argument was repacked from.  I % 16 == 0."""
+    N = scales.shape[1]
+    inter = N // 2
+    if N % 32 or qweight.shape[1] * 8 != N:
+        raise ValueError(f"interleave_gate_up: need 2I columns with I % 16 == 0, got N = {N}")
+    grp = torch.arange(N // 16, device=scales.device)
+    src = torch.where(grp % 2 == 0, grp // 2, inter // 16 + grp // 2)                 # source 16-column group of each output group
+    cols = (src.view(-1, 1) * 16 + torch.arange(16, device=scales.device)).reshape(-1)
+    words = (src.view(-1, 1) * 2 + torch.arange(2, device=scales.device)).reshape(-1)   # 8 logical columns per int32
+    return qweight[:, words].contiguous(), scales[:, cols].contiguous(), qzeros[:, words].contiguous()
+
+
+def gemv_repacked_fused(packed: torch.Tensor, K: int, N: int, group_size: int, x: Optional[torch.Tensor] = None,
+                        norm: Optional[tuple] = None, silu_mul: bool = False):
+    """Repacked decode GEMV with RMSNorm(+residual) prologue and / or SiLU-mul epilogue (include/awq_aux.h).
+    norm = (h, delta, weight, eps): returns (y, h + delta); else x is the input and (y, None) is returned.
+    Returns None when there is no fused kernel for the shape (callers run the separate ops)."""
+    src = norm[0] if norm is not None else x
+    assert src is not None and src.dtype == torch.float16 and src.dim() == 2 and src.is_contiguous() and src.shape[1] == K
+    M = src.shape[0]
+    dev = src.device
+    y = torch.empty((M, N // 2 if silu_mul else N), dtype=torch.float16, device=dev)
+    h_out = None
+    if norm is not None:
+        h, delta, w, eps = norm
+        assert delta.shape == h.shape and delta.is_contiguous() and w.is_contiguous() and w.shape == (K,)
+        h_out = torch.empty_like(h)
+        args = (_vp(h), _vp(delta), _vp(w), _vp(h_out), float(eps))
+    else:
+        args = (None, None, None, None, 0.0)
+    rc = _lib.load().awq_aux_gemv_repacked_fused(_vp(x), K, _vp(packed), _vp(y), M, K, N, group_size, _lib.DTYPE_F16, *args,
+                                                 1 if silu_mul else 0, _stream(src))
+    if rc == _lib.ERR_BAD_VARIANT:
+        return None
+    _lib.check(rc, "awq_aux_gemv_repacked_fused")
+    return y, h_out

@@ -23,6 +23,13 @@ struct GemmArgs {
   int dtype;
   int64_t tune;
   hipStream_t stream;
+  // optional fusions of the repacked decode GEMV (awq_aux.h); all zero = the plain operator
+  const void* norm_h = nullptr;      // x = rmsnorm(norm_h + norm_delta) * norm_w is built in the prologue (a.x is ignored)
+  const void* norm_delta = nullptr;
+  const void* norm_w = nullptr;
+  void* norm_h_out = nullptr;        // norm_h + norm_delta, [M, K] with row stride ldx (must not alias norm_h)
+  float norm_eps = 0.f;
+  int silu_mul = 0;                  // 1: column groups alternate gate / up; y = silu(gate) * up, [M, N / 2]
 };
 
 int launch_dequantize(const int32_t* qweight, const void* scales, const int32_t* qzeros, void* out, int64_t K,
@@ -47,6 +54,7 @@ bool repacked_supported(int64_t K, int64_t N, int64_t g, int dtype);
 int launch_repack(const int32_t* qweight, const void* scales, const int32_t* qzeros, void* packed, int64_t K, int64_t N, int64_t g,
                   int dtype, hipStream_t stream);
 int launch_gemv_repacked(const GemmArgs& a, const void* packed);
+int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed);   // norm prologue and / or SiLU-mul epilogue (awq_repacked_fused.hip)
 int launch_gemm_repacked_tiled(const GemmArgs& a, const void* packed);   // any M, MFMA-bound prefill shapes
 
 }  // namespace awq

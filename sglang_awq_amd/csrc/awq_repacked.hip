@@ -21,12 +21,9 @@
 // consecutive k-block ranges and are summed in fixed order through LDS; y is written directly.
 #include <cstdlib>
 
-#include "awq_device.h"
-#include "awq_kernels.h"
+#include "awq_repacked_gemv.h"
 
 namespace awq {
-
-constexpr int kRpMaxG = 8;
 
 // ------------------------------------------------------------------------------------------ repack
 __global__ __launch_bounds__(256) void repack_qweight_kernel(const uint32_t* __restrict__ qw, uint32_t* __restrict__ out,
@@ -69,161 +66,6 @@ __global__ __launch_bounds__(256) void repack_zs_kernel(const uint32_t* __restri
       v = ((0x6400u | (uint32_t)z) << 16) | scales[(size_t)grp * C * 8 + n];
     }
     out[idx] = v;
-  }
-}
-
-// ------------------------------------------------------------------------------------------ GEMV
-// 8 weights of one column (one dword) -> the 4 packed k-pairs of an MFMA B fragment
-__device__ __forceinline__ u32x4_t rp_dequant(uint32_t w, half2_t z1024, half2_t z64, half2_t s2) {
-  const half2_t sixteenth = {(half_t)0.0625f, (half_t)0.0625f};
-  const uint32_t magic = kMagicF16;
-  const uint32_t w8 = w >> 8;
-  const half2_t d0 = as_h2(and_or(w, kLoNib, magic)) - z1024;
-  const half2_t d1 = __builtin_elementwise_fma(as_h2(and_or(w, kHiNib, magic)), sixteenth, -z64);
-  const half2_t d2 = as_h2(and_or(w8, kLoNib, magic)) - z1024;
-  const half2_t d3 = __builtin_elementwise_fma(as_h2(and_or(w8, kHiNib, magic)), sixteenth, -z64);
-  return (u32x4_t){as_u32(d0 * s2), as_u32(d1 * s2), as_u32(d2 * s2), as_u32(d3 * s2)};
-}
-
-constexpr int kRpMaxMT = 2;   // MFMA row tiles: M <= 16 * MT
-struct RpBlock {            // one k-block (128 rows) of a strip, in registers
-  u32x4_t w[kRpMaxG];       // per column group: 4 dwords = 4 k-steps
-  uint32_t zs[kRpMaxG];     // per column group: (1024 + z | s) of this lane's column
-  u32x4_t xa[4][kRpMaxMT];  // x fragments of the 4 k-steps, per row tile
-};
-
-template <int G, bool NT, int MT>
-__device__ __forceinline__ void rp_load(RpBlock& b, const u32x4_t* __restrict__ qw_r, const uint32_t* __restrict__ zs_r,
-                                        const uint16_t* __restrict__ x, int64_t ldx, int cg0, int KB, int groups, int g, int kb,
-                                        int lane, const int (&xr)[kRpMaxMT]) {
-  const int q = lane >> 4, r = lane & 15;
-#pragma unroll
-  for (int c = 0; c < G; ++c) {
-    const u32x4_t* p = qw_r + ((size_t)(cg0 + c) * KB + kb) * 64 + lane;
-    b.w[c] = NT ? __builtin_nontemporal_load(p) : *p;      // streamed once: keep it out of the caches' way
-  }
-  const int grp = (kb * 128) / g;                      // g >= 128 here (smaller groups take the per-k-step path below)
-#pragma unroll
-  for (int c = 0; c < G; ++c) b.zs[c] = zs_r[((size_t)(cg0 + c) * groups + grp) * 16 + r];
-#pragma unroll
-  for (int d = 0; d < 4; ++d)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) b.xa[d][mt] = *(const u32x4_t*)(x + (size_t)xr[mt] * ldx + kb * 128 + d * 32 + q * 8);
-}
-
-template <int G, int MT>
-__device__ __forceinline__ void rp_compute(const RpBlock& b, float4_t (&acc)[kRpMaxMT][kRpMaxG]) {
-  const half2_t c960 = {(half_t)960.f, (half_t)960.f};
-#pragma unroll
-  for (int c = 0; c < G; ++c) {
-    const half2_t s2 = as_h2(pack_lo16(b.zs[c], b.zs[c]));
-    const half2_t z1024 = as_h2(pack_hi16(b.zs[c], b.zs[c]));
-    const half2_t z64 = z1024 - c960;                  // exact: (1024 + z) - 960
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      const u32x4_t frag = rp_dequant(b.w[c][d], z1024, z64, s2);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)   // the dequantised fragment is shared by every row tile
-        acc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, b.xa[d][mt]), __builtin_bit_cast(half8_t, frag), acc[mt][c], 0, 0, 0);
-    }
-  }
-}
-
-// T = k-blocks per wave when it is small enough to issue every load up front (straight-line code, exact
-// counted waits); T == 0: any count, double-buffered loop.
-template <int G, int T, int W, bool NT, int MT>
-__global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(const uint16_t* __restrict__ x, int64_t ldx,
-                                                                          const u32x4_t* __restrict__ qw_r,
-                                                                          const uint32_t* __restrict__ zs_r,
-                                                                          const void* __restrict__ bias, void* __restrict__ y,
-                                                                          int M, int K, int N, int g, int NG, int per_wave,
-                                                                          unsigned long long* __restrict__ dbg) {
-  extern __shared__ __attribute__((aligned(16))) float red[];    // [W][M][16 G]
-#define RP_STAMP(slot) do { if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-  RP_STAMP(0);
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int q = lane >> 4, r = lane & 15;
-  const int KB = K / 128, groups = K / g;
-  int cg0 = blockIdx.x * G;
-  if (cg0 + G > NG) cg0 = NG - G;                      // last strip overlaps its neighbour (same values written twice)
-  int xr[kRpMaxMT];
-#pragma unroll
-  for (int mt = 0; mt < kRpMaxMT; ++mt) xr[mt] = mt * 16 + r < M ? mt * 16 + r : M - 1;
-
-  float4_t acc[kRpMaxMT][kRpMaxG];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int c = 0; c < G; ++c) acc[mt][c] = (float4_t){0.f, 0.f, 0.f, 0.f};
-
-  const int kb_begin = wave * per_wave;
-  int kb_end = kb_begin + per_wave;
-  if (kb_end > KB) kb_end = KB;
-
-  if constexpr (T > 0) {
-    RpBlock buf[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const int kb = kb_begin + t < KB ? kb_begin + t : KB - 1;         // clamped: re-read, then weighted by x = 0
-      rp_load<G, NT, MT>(buf[t], qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    RP_STAMP(1);
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      if (kb_begin + t >= KB) {
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) buf[t].xa[d][mt] = (u32x4_t){0u, 0u, 0u, 0u};
-      }
-      rp_compute<G, MT>(buf[t], acc);
-      __builtin_amdgcn_sched_barrier(0);
-      if (t == 0) RP_STAMP(2);
-    }
-  } else {
-    // steady state has no branch between a load and its use (exact counted waits); only the prologue and the
-    // <= 3-block tail are conditional
-    RpBlock A, B;
-    int kb = kb_begin;
-    if (kb < kb_end) rp_load<G, NT, MT>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
-    if (kb + 1 < kb_end) rp_load<G, NT, MT>(B, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 1, lane, xr);
-    while (kb + 3 < kb_end) {
-      rp_compute<G, MT>(A, acc);
-      rp_load<G, NT, MT>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 2, lane, xr);
-      rp_compute<G, MT>(B, acc);
-      rp_load<G, NT, MT>(B, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 3, lane, xr);
-      kb += 2;
-    }
-    if (kb < kb_end) rp_compute<G, MT>(A, acc);
-    if (kb + 2 < kb_end) rp_load<G, NT, MT>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 2, lane, xr);
-    if (kb + 1 < kb_end) rp_compute<G, MT>(B, acc);
-    if (kb + 2 < kb_end) rp_compute<G, MT>(A, acc);
-  }
-
-  RP_STAMP(3);
-  // D[m = 4q + i][n = r] per column group -> LDS, summed over the waves in fixed order
-  const int SW = 16 * G;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int c = 0; c < G; ++c)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = mt * 16 + 4 * q + i;
-        if (m < M) red[((size_t)wave * M + m) * SW + c * 16 + r] = acc[mt][c][i];
-      }
-  __syncthreads();
-  RP_STAMP(4);
-  for (int idx = threadIdx.x; idx < M * SW; idx += W * 64) {
-    const int m = idx / SW, col = idx - m * SW;
-    const int n = cg0 * 16 + col;
-    if (n >= N) continue;
-    float v = red[(size_t)m * SW + col];
-#pragma unroll
-    for (int w = 1; w < W; ++w) v += red[((size_t)w * M + m) * SW + col];
-    store_output<AWQ_DTYPE_F16>(y, (size_t)m * N + n, v, bias, n);
   }
 }
 
@@ -376,23 +218,22 @@ int launch_gemm_repacked_tiled(const GemmArgs& a, const void* packed) {
 }
 
 // ------------------------------------------------------------------------------------------ host
-static inline int rp_groups(int N) { return (N + 15) / 16; }
 
 size_t repacked_bytes(int64_t K, int64_t N, int64_t g) {
   if (K <= 0 || N <= 0 || g <= 0 || K % 128 || K % g) return 0;
-  const size_t NG = (size_t)rp_groups((int)N);
+  const size_t NG = (size_t)rp_groups(N);
   return NG * (size_t)(K / 128) * 1024 + NG * (size_t)(K / g) * 64;
 }
 
 bool repacked_supported(int64_t K, int64_t N, int64_t g, int dtype) {
   return dtype == AWQ_DTYPE_F16 && K % 128 == 0 && g % 128 == 0 && K % g == 0 && N % 8 == 0 && K > 0 && N > 0 &&
-         rp_groups((int)N) >= 1;
+         rp_groups(N) >= 1;
 }
 
 int launch_repack(const int32_t* qweight, const void* scales, const int32_t* qzeros, void* packed, int64_t K, int64_t N, int64_t g,
                   int dtype, hipStream_t stream) {
   if (!repacked_supported(K, N, g, dtype)) return AWQ_ERR_BAD_VARIANT;
-  const int NG = rp_groups((int)N), C = (int)(N / 8);
+  const int NG = rp_groups(N), C = (int)(N / 8);
   uint32_t* qw_r = (uint32_t*)packed;
   uint32_t* zs_r = qw_r + (size_t)NG * (K / 128) * 256;
   hipLaunchKernelGGL(repack_qweight_kernel, dim3(2048), dim3(256), 0, stream, (const uint32_t*)qweight, qw_r, (int)K, C, NG);
@@ -402,53 +243,8 @@ int launch_repack(const int32_t* qweight, const void* scales, const int32_t* qze
 }
 
 // diagnostic only (tools/kbench rstamps): when set, workgroups write 100 MHz-clock stamps into this device buffer
-static unsigned long long* g_rp_stamp_buffer = nullptr;
+unsigned long long* g_rp_stamp_buffer = nullptr;
 extern "C" void awq_debug_set_stamp_buffer(void* p) { g_rp_stamp_buffer = (unsigned long long*)p; }
-
-// Which (waves, row tiles, strip width G, straight-line depth T) instantiations fit their register budget
-// (128 VGPRs at 16 waves, 256 at 8) without scratch — from hipcc's -Rpass-analysis=kernel-resource-usage
-// (tools/rp_resources.py prints the table).  A spilling variant is never built nor chosen: G = 3, T = 4 at
-// 16 waves spills 52 B / lane and ran 8192 x 10240 at 18.1 us instead of 13.0.
-constexpr bool rp_fits(int W, int MT, int G, int T) {
-  if (MT == 2) return T == 0 || (T == 4 && G <= 5);
-  if (W == 16) return G <= (T == 0 ? 5 : T <= 2 ? 8 : T == 3 ? 4 : T == 4 ? 2 : T == 5 ? 1 : 0);
-  return G <= (T <= 4 ? 8 : T == 5 ? 6 : 4);
-}
-
-template <int G, int W, bool NT, int MT>
-static void rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wave, int T, int nwg, size_t lds) {
-  const u32x4_t* qw_r = (const u32x4_t*)packed;
-  const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
-  dim3 grid(nwg), block(W * 64);
-#define RP_GO(TT)                                                                                                                  \
-  if constexpr (rp_fits(W, MT, G, TT) && (MT == 1 || TT == 0 || TT == 4))                                                            \
-    hipLaunchKernelGGL((gemv_repacked_kernel<G, TT, W, NT, MT>), grid, block, lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r, \
-                       a.bias, a.y, a.M, a.K, a.N, a.g, NG, per_wave, g_rp_stamp_buffer)
-  switch (T) {
-    case 1: RP_GO(1); break;
-    case 2: RP_GO(2); break;
-    case 3: RP_GO(3); break;
-    case 4: RP_GO(4); break;
-    case 5: RP_GO(5); break;
-    case 6: RP_GO(6); break;
-    default: RP_GO(0); break;
-  }
-#undef RP_GO
-}
-
-template <int W, bool NT, int MT>
-static void rp_launch_g(int G, const GemmArgs& a, const void* packed, int NG, int per_wave, int T, int nwg, size_t lds) {
-  switch (G) {
-    case 1: rp_launch<1, W, NT, MT>(a, packed, NG, per_wave, T, nwg, lds); break;
-    case 2: rp_launch<2, W, NT, MT>(a, packed, NG, per_wave, T, nwg, lds); break;
-    case 3: rp_launch<3, W, NT, MT>(a, packed, NG, per_wave, T, nwg, lds); break;
-    case 4: rp_launch<4, W, NT, MT>(a, packed, NG, per_wave, T, nwg, lds); break;
-    case 5: rp_launch<5, W, NT, MT>(a, packed, NG, per_wave, T, nwg, lds); break;
-    case 6: rp_launch<6, W, NT, MT>(a, packed, NG, per_wave, T, nwg, lds); break;
-    case 7: rp_launch<7, W, NT, MT>(a, packed, NG, per_wave, T, nwg, lds); break;
-    default: rp_launch<8, W, NT, MT>(a, packed, NG, per_wave, T, nwg, lds); break;
-  }
-}
 
 static int rp_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 

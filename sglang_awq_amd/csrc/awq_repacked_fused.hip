@@ -1,0 +1,71 @@
+// Fused variants of the repacked decode GEMV for the decode harness (C entry in awq_aux.h):
+//   * norm prologue   x = RMSNorm(h + delta) * w   (the reference's RMSNorm-with-residual before qkv_proj /
+//                     gate_up_proj, python/sglang/srt/models/llama.py:277-290), computed by every workgroup in LDS
+//                     while its weight loads are in flight — removes a ~4.7 us dependent launch per use;
+//   * SiLU-mul epilogue  act = silu(gate) * up   (layers/activation.py SiluAndMul after gate_up_proj) on a copy
+//                     repacked from column-interleaved gate / up groups, so both halves of a pair sit in one strip.
+// Same kernel template as the plain operator (awq_repacked_gemv.h); only 16-wave, straight-line, one-row-tile
+// instantiations exist, anything else returns AWQ_ERR_BAD_VARIANT and the caller runs the unfused sequence.
+#include "../../include/awq_aux.h"
+#include "awq_repacked_gemv.h"
+
+namespace awq {
+
+template <int PRO, int EPI>
+static void fused_go(int G, const GemmArgs& a, const void* packed, int NG, int per_wave, int T, int nwg, size_t lds) {
+  rp_launch_g<16, true, 1, PRO, EPI>(G, a, packed, NG, per_wave, T, nwg, lds);
+}
+
+int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed) {
+  const bool norm = a.norm_h != nullptr;
+  if (!norm && !a.silu_mul) return launch_gemv_repacked(a, packed);
+  if (!repacked_supported(a.K, a.N, a.g, a.dtype) || a.M < 1 || a.M > 16 || a.ldx % 8) return AWQ_ERR_BAD_VARIANT;
+  if (!norm && (((uintptr_t)a.x) & 15)) return AWQ_ERR_BAD_VARIANT;
+  if (a.silu_mul && a.N % 32) return AWQ_ERR_BAD_VARIANT;                  // whole (gate, up) pairs of 16-column groups
+  constexpr int W = 16;
+  const int NG = rp_groups(a.N), KB = a.K / 128;
+  int G = (NG + 255) / 256;
+  if (a.silu_mul && (G & 1)) ++G;
+  if (G > kRpMaxG || G > NG) return AWQ_ERR_BAD_VARIANT;
+  const int nwg = (NG + G - 1) / G;
+  const int T = (KB + W - 1) / W;                                            // = per_wave: straight-line variants only
+  int PRO = 0;
+  if (norm) {
+    if (!a.norm_delta || !a.norm_w || !a.norm_h_out || a.norm_h_out == a.norm_h || a.K % 512) return AWQ_ERR_BAD_VARIANT;
+    if ((((uintptr_t)a.norm_h) | ((uintptr_t)a.norm_delta) | ((uintptr_t)a.norm_w) | ((uintptr_t)a.norm_h_out)) & 15) return AWQ_ERR_BAD_VARIANT;
+    const int64_t chunks = (int64_t)a.M * (a.K / 8);
+    PRO = chunks <= W * 64 ? 1 : chunks <= 2 * W * 64 ? 2 : 0;
+    if (!PRO) return AWQ_ERR_BAD_VARIANT;
+  }
+  if (!rp_fits_fused(G, T, PRO, a.silu_mul)) return AWQ_ERR_BAD_VARIANT;
+  size_t lds = (size_t)W * a.M * 16 * G * sizeof(float);
+  if (norm) lds += (size_t)a.M * (a.K + 8) * 2 + (size_t)PRO * W * sizeof(float);
+  if (lds > 64 * 1024) return AWQ_ERR_BAD_VARIANT;
+  if (a.silu_mul) {
+    if (PRO == 0) fused_go<0, 1>(G, a, packed, NG, T, T, nwg, lds);
+    else if (PRO == 1) fused_go<1, 1>(G, a, packed, NG, T, T, nwg, lds);
+    else fused_go<2, 1>(G, a, packed, NG, T, T, nwg, lds);
+  } else {
+    if (PRO == 1) fused_go<1, 0>(G, a, packed, NG, T, T, nwg, lds);
+    else fused_go<2, 0>(G, a, packed, NG, T, T, nwg, lds);
+  }
+  return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
+
+}  // namespace awq
+
+extern "C" int awq_aux_gemv_repacked_fused(const void* x, int64_t ldx, const void* packed, void* y, int64_t M, int64_t K, int64_t N,
+                                           int64_t group_size, int dtype, const void* norm_h, const void* norm_delta,
+                                           const void* norm_w, void* norm_h_out, float norm_eps, int silu_mul, void* stream) {
+  if (!packed || !y || (!x && !norm_h)) return AWQ_ERR_NULL_POINTER;
+  if (K <= 0 || N <= 0 || group_size <= 0 || N % 8 || K % group_size || M <= 0 || ldx < K) return AWQ_ERR_BAD_SHAPE;
+  if ((((uintptr_t)packed) & 15) || (((uintptr_t)y) & 1)) return AWQ_ERR_MISALIGNED;
+  awq::GemmArgs a;
+  a.x = x; a.ldx = ldx; a.qweight = nullptr; a.scales = nullptr; a.qzeros = nullptr; a.bias = nullptr; a.y = y;
+  a.workspace = nullptr; a.workspace_bytes = 0;
+  a.M = (int)M; a.K = (int)K; a.N = (int)N; a.g = (int)group_size; a.dtype = dtype; a.tune = 0;
+  a.stream = (hipStream_t)stream;
+  a.norm_h = norm_h; a.norm_delta = norm_delta; a.norm_w = norm_w; a.norm_h_out = norm_h_out; a.norm_eps = norm_eps;
+  a.silu_mul = silu_mul;
+  return awq::launch_gemv_repacked_fused(a, packed);
+}

@@ -88,21 +88,58 @@ class LlamaDecoderLayer(torch.nn.Module):
         self.register_buffer("k_cache", torch.zeros(max_batch, self.num_kv_heads, max_seq, self.head_dim, dtype=dtype), persistent=False)
         self.register_buffer("v_cache", torch.zeros(max_batch, self.num_kv_heads, max_seq, self.head_dim, dtype=dtype), persistent=False)
 
+    @staticmethod
+    def _awq_dims(lin):
+        K = lin.qweight.shape[0]
+        return K, lin.qweight.shape[1] * 8, K // lin.scales.shape[0]
+
+    def _gate_up_interleaved(self):
+        """Second repacked copy of gate_up whose 16-column groups alternate gate / up (built once, lazily): lets the
+        GEMV's epilogue apply SiLU-mul.  None when the shape has no repacked form."""
+        if not hasattr(self, "_gu_il"):
+            from . import aux_ops, ops
+
+            self._gu_il = None
+            lin = self.gate_up_proj
+            if getattr(lin, "awq_packed", None) is not None and lin.bias is None and (lin.qweight.shape[1] * 8) % 32 == 0:
+                self._gu_il = ops.awq_repack(*aux_ops.interleave_gate_up(lin.qweight.data, lin.scales.data, lin.qzeros.data))
+        return self._gu_il
+
     def forward_fused(self, h, delta, pos, cos_table, sin_table):
-        """Same layer with the elementwise neighbours fused (aux_ops): h is the residual stream (updated in place),
-        delta the previous layer's MLP output still to be added.  Returns this layer's MLP output (the next delta)."""
+        """Same layer with its elementwise neighbours fused: h is the residual stream, delta the previous layer's MLP
+        output still to be added.  Returns (h + delta + attention output, this layer's MLP output = the next delta).
+        Five launches at decode batch sizes: qkv GEMV (RMSNorm + residual in its prologue), attention (RoPE + KV write
+        inside), o_proj GEMV, gate_up GEMV (RMSNorm + residual prologue, SiLU-mul epilogue), down_proj GEMV; shapes
+        without a fused kernel fall back to the separate launches."""
         from . import aux_ops
 
         B = h.shape[0]
-        x = aux_ops.add_rmsnorm(h, delta, self.input_layernorm, self.cfg.rms_norm_eps)
-        qkv, _ = self.qkv_proj(x)
+        eps = self.cfg.rms_norm_eps
+        qkv = None
+        packed = getattr(self.qkv_proj, "awq_packed", None)
+        if packed is not None and self.qkv_proj.bias is None:
+            r = aux_ops.gemv_repacked_fused(packed, *self._awq_dims(self.qkv_proj), norm=(h, delta, self.input_layernorm, eps))
+            if r is not None:
+                qkv, h = r
+        if qkv is None:
+            x = aux_ops.add_rmsnorm(h, delta, self.input_layernorm, eps)          # h += delta in place
+            qkv, _ = self.qkv_proj(x)
         attn = aux_ops.decode_attention(qkv, pos, cos_table, sin_table, self.k_cache, self.v_cache, self.num_heads, self.num_kv_heads,
                                         self.head_dim)
         o, _ = self.o_proj(attn.reshape(B, self.q_size))
-        x = aux_ops.add_rmsnorm(h, o, self.post_attention_layernorm, self.cfg.rms_norm_eps)
-        gu, _ = self.gate_up_proj(x)
-        d, _ = self.down_proj(aux_ops.silu_mul(gu))
-        return d
+        act = None
+        gu_il = self._gate_up_interleaved()
+        if gu_il is not None:
+            r = aux_ops.gemv_repacked_fused(gu_il, *self._awq_dims(self.gate_up_proj), norm=(h, o, self.post_attention_layernorm, eps),
+                                            silu_mul=True)
+            if r is not None:
+                act, h = r
+        if act is None:
+            x = aux_ops.add_rmsnorm(h, o, self.post_attention_layernorm, eps)
+            gu, _ = self.gate_up_proj(x)
+            act = aux_ops.silu_mul(gu)
+        d, _ = self.down_proj(act)
+        return h, d
 
     def forward(self, h: torch.Tensor, pos: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         B = h.shape[0]
@@ -144,6 +181,7 @@ class LlamaForCausalLM(torch.nn.Module):
         self.register_buffer("cos_table", freqs.cos(), persistent=False)
         self.register_buffer("sin_table", freqs.sin(), persistent=False)
         self.register_buffer("arange_seq", torch.arange(max_seq), persistent=False)
+        self.register_buffer("zero_delta", torch.zeros(max_batch, cfg.hidden_size, dtype=dtype), persistent=False)
 
     @torch.no_grad()
     def init_synthetic_(self, seed: int = 0):
@@ -172,9 +210,9 @@ class LlamaForCausalLM(torch.nn.Module):
             from . import aux_ops
 
             h = self.embed_tokens[tokens]                       # residual stream, updated in place by add_rmsnorm
-            delta = None
+            delta = self.zero_delta[:h.shape[0]]
             for layer in self.layers:
-                delta = layer.forward_fused(h, delta, pos, self.cos_table, self.sin_table)
+                h, delta = layer.forward_fused(h, delta, pos, self.cos_table, self.sin_table)
             h = aux_ops.add_rmsnorm(h, delta, self.norm, self.cfg.rms_norm_eps)
             return torch.matmul(h, self.lm_head.t())
         h = self.embed_tokens[tokens]

@@ -14,7 +14,7 @@ import torch
 
 from oracle import awq_ref, c_oracle
 from sglang_awq_amd import _lib, synth
-from tests.util import TORCH_DT, assert_gemm_close, bits, to_np, to_torch
+from tests.util import TORCH_DT, assert_gemm_close, bits, to_np, to_torch, ulp
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -168,6 +168,78 @@ def test_gemm_repacked_vs_oracle(ops, M):
         assert torch.equal(yb, to_torch(y, DEV) + to_torch(b, DEV))
     assert ops.awq_repack(*_dev(*synth.make_awq_weights(256, 64, 32, "f16", "A", 1))) is None        # g = 32: not supported
     assert ops.awq_repack(*_dev(*synth.make_awq_weights(256, 64, 128, "bf16", "A", 1))) is None      # bf16: not supported
+
+
+def _interleave_np(qw, s, qz):
+    """numpy restatement of aux_ops.interleave_gate_up: 16-column groups alternate gate / up."""
+    N = s.shape[1]
+    grp = np.arange(N // 16)
+    src = np.where(grp % 2 == 0, grp // 2, N // 32 + grp // 2)
+    cols = (src[:, None] * 16 + np.arange(16)).reshape(-1)
+    words = (src[:, None] * 2 + np.arange(2)).reshape(-1)
+    return qw[:, words], s[:, cols], qz[:, words]
+
+
+@pytest.mark.parametrize("M", [1, 2, 4])
+def test_gemv_repacked_fused_vs_oracle(ops, M):
+    """Decode-harness fusions of the repacked GEMV (include/awq_aux.h): RMSNorm(+residual) prologue and SiLU-mul
+    epilogue, separately and together, against numpy restatements around the oracle GEMM.  h + delta is bit-exact;
+    y is held to the GEMM bound with the prologue's x rebuilt in numpy (rsq / summation-order differences can move
+    an x element by one fp16 ulp, far below the 1e-3 allowance)."""
+    from sglang_awq_amd import aux_ops
+
+    eps = 1e-5
+    for (K, N, g) in [(512, 64, 128), (1024, 1056 * 2, 128), (4096, 12288, 128), (4096, 22016, 128), (2048, 4096, 2048)]:
+        qw, s, qz = synth.make_awq_weights(K, N, g, "f16", "A", seed=M * 31 + K + N)
+        h = synth.make_activations(M, K, "f16", "A", seed=M + K + 3)
+        delta = synth.make_activations(M, K, "f16", "A", seed=M + K + 4)
+        w = (1.0 + 0.25 * synth.make_activations(1, K, "f16", "A", seed=K + 5)[0].astype(np.float32)).astype(np.float16)
+        v = (h + delta).astype(np.float16)                                         # fp16 add
+        inv = 1.0 / np.sqrt((v.astype(np.float64) ** 2).mean(-1, keepdims=True) + eps)
+        xn = (v.astype(np.float32) * inv.astype(np.float32)).astype(np.float16) * w   # fp16(v * inv) * w, fp16 multiply
+        dev = [to_torch(t, DEV) for t in (h, delta, w)]
+        packed = ops.awq_repack(*_dev(qw, s, qz))
+        qwi, si, qzi = _interleave_np(qw, s, qz)
+        ti = aux_ops.interleave_gate_up(*_dev(qw, s, qz))
+        assert all(torch.equal(a, to_torch(np.ascontiguousarray(b), DEV)) for a, b in zip(ti, (qwi, si, qzi)))
+        packed_il = ops.awq_repack(*ti)
+
+        def silu_mul(gu_exact):           # gate_up rounded to fp16, silu in fp32 rounded to fp16, fp16 multiply
+            gu = gu_exact.astype(np.float16)
+            gate, up = gu[:, :N // 2].astype(np.float32), gu[:, N // 2:]
+            return (gate / (1.0 + np.exp(-gate))).astype(np.float16) * up
+
+        # 1. norm prologue only
+        r = aux_ops.gemv_repacked_fused(packed, K, N, g, norm=(dev[0], dev[1], dev[2], eps))
+        if M * K <= 16384 and K % 512 == 0:
+            assert r is not None, f"no fused kernel for M={M} K={K} N={N}"
+            y, h_out = r
+            assert np.array_equal(to_np(h_out), v)
+            _, exact = c_oracle.gemm(xn, qw, s, qz, want_exact=True)
+            assert_gemm_close(to_np(y), exact, "f16", atol=2e-3, what=f"norm-fused M={M} K={K} N={N}")
+        else:
+            assert r is None
+        # 2. SiLU-mul epilogue only (x given)
+        x = synth.make_activations(M, K, "f16", "A", seed=M + K + 6)
+        r = aux_ops.gemv_repacked_fused(packed_il, K, N, g, x=to_torch(x, DEV), silu_mul=True)
+        assert r is not None
+        _, exact = c_oracle.gemm(x, qw, s, qz, want_exact=True)
+        want = silu_mul(exact).astype(np.float64)
+        got = to_np(r[0]).astype(np.float64)
+        assert got.shape == (M, N // 2)
+        tol = 2.0 * ulp(want, "f16") + 2e-3 * (1.0 + np.abs(exact[:, N // 2:]))     # silu' <= 1.1: gate error 1e-3 scales by |up|
+        assert np.all(np.abs(got - want) <= tol), f"silu-fused M={M} K={K} N={N}: worst {np.abs(got - want).max():.3e}"
+        assert float((got != want).mean()) < 0.05
+        # 3. both
+        r = aux_ops.gemv_repacked_fused(packed_il, K, N, g, norm=(dev[0], dev[1], dev[2], eps), silu_mul=True)
+        if M * K <= 16384 and K % 512 == 0:
+            assert r is not None
+            _, exact = c_oracle.gemm(xn, qw, s, qz, want_exact=True)
+            want = silu_mul(exact).astype(np.float64)
+            got = to_np(r[0]).astype(np.float64)
+            tol = 2.0 * ulp(want, "f16") + 4e-3 * (1.0 + np.abs(exact[:, N // 2:]))
+            assert np.all(np.abs(got - want) <= tol), f"norm+silu M={M} K={K} N={N}: worst {np.abs(got - want).max():.3e}"
+            assert np.array_equal(to_np(r[1]), v)
 
 
 def test_gemm_repacked_tiled_vs_oracle(ops):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Print VGPR / scratch use of every gemv_repacked_kernel<G, T, W, NT, MT> instantiation (hipcc resource remarks).
+"""Print VGPR / scratch use of every gemv_repacked_kernel<G, T, W, NT, MT, PRO, EPI> instantiation (hipcc resource remarks).
 
 The launch heuristic's `rp_fits` table in sglang_awq_amd/csrc/awq_repacked.hip is derived from this output;
 run it after touching the kernel.  Exit status 1 if any built instantiation uses scratch.
@@ -7,32 +7,34 @@ run it after touching the kernel.  Exit status 1 if any built instantiation uses
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "sglang_awq_amd", "csrc", "awq_repacked.hip")
+SRCS = [os.path.join(ROOT, "sglang_awq_amd", "csrc", f) for f in ("awq_repacked.hip", "awq_repacked_fused.hip")]
 
 
 def main():
+    txt = ""
     with tempfile.TemporaryDirectory() as d:
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-ffp-contract=on",
-               "-Rpass-analysis=kernel-resource-usage", "-c", SRC, "-o", os.path.join(d, "x.o")]
-        txt = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
+        for src in SRCS:
+            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-ffp-contract=on",
+                   "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.path.join(d, "x.o")]
+            txt += subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
     rows = []
     for blk in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
         name = blk.split()[0]
-        m = re.search(r"gemv_repacked_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)E", name)
+        m = re.search(r"gemv_repacked_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
         if not m:
             continue
-        G, T, W, NT, MT = map(int, m.groups())
+        G, T, W, NT, MT, PRO, EPI = map(int, m.groups())
 
         def field(k):
             mm = re.search(k + r": (\d+)", blk)
             return int(mm.group(1)) if mm else -1
 
-        rows.append((MT, W, NT, G, T, field("VGPRs"), field(r"ScratchSize \[bytes/lane\]"), field(r"Occupancy \[waves/SIMD\]")))
+        rows.append((PRO, EPI, MT, W, NT, G, T, field("VGPRs"), field(r"ScratchSize \[bytes/lane\]"), field(r"Occupancy \[waves/SIMD\]")))
     rows.sort()
     bad = 0
     for r in rows:
-        print("MT%d W%-2d NT%d G%d T%d  vgpr %3d  scratch %4d  occupancy %d" % r)
-        bad += r[6] > 0
+        print("PRO%d EPI%d MT%d W%-2d NT%d G%d T%d  vgpr %3d  scratch %4d  occupancy %d" % r)
+        bad += r[8] > 0
     print(f"{len(rows)} instantiations, {bad} with scratch")
     return 1 if bad else 0
 
