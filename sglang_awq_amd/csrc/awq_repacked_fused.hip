@@ -31,23 +31,25 @@ int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed) {
   const int T = (KB + W - 1) / W;                                            // = per_wave: straight-line variants only
   int PRO = 0;
   if (norm) {
-    if (!a.norm_delta || !a.norm_w || !a.norm_h_out || a.norm_h_out == a.norm_h || a.K % 512) return AWQ_ERR_BAD_VARIANT;
+    if (!a.norm_delta || !a.norm_w || !a.norm_h_out || a.norm_h_out == a.norm_h) return AWQ_ERR_BAD_VARIANT;
     if ((((uintptr_t)a.norm_h) | ((uintptr_t)a.norm_delta) | ((uintptr_t)a.norm_w) | ((uintptr_t)a.norm_h_out)) & 15) return AWQ_ERR_BAD_VARIANT;
-    const int64_t chunks = (int64_t)a.M * (a.K / 8);
-    PRO = chunks <= W * 64 ? 1 : chunks <= 2 * W * 64 ? 2 : 0;
+    const int per_lane = (a.M * T * 16 + 63) / 64;                           // chunks of 8 halves per lane of a wave's own columns
+    PRO = per_lane <= 1 ? 1 : per_lane <= 2 ? 2 : per_lane <= 4 ? 4 : 0;
     if (!PRO) return AWQ_ERR_BAD_VARIANT;
   }
   if (!rp_fits_fused(G, T, PRO, a.silu_mul)) return AWQ_ERR_BAD_VARIANT;
   size_t lds = (size_t)W * a.M * 16 * G * sizeof(float);
-  if (norm) lds += (size_t)a.M * (a.K + 8) * 2 + (size_t)PRO * W * sizeof(float);
-  if (lds > 64 * 1024) return AWQ_ERR_BAD_VARIANT;
+  if (norm) lds += (size_t)W * a.M * (T * 128 + 8) * 2 + (size_t)W * PRO * 4 * sizeof(float);
+  if (lds > (size_t)kRpMaxLds) return AWQ_ERR_BAD_VARIANT;
   if (a.silu_mul) {
     if (PRO == 0) fused_go<0, 1>(G, a, packed, NG, T, T, nwg, lds);
     else if (PRO == 1) fused_go<1, 1>(G, a, packed, NG, T, T, nwg, lds);
-    else fused_go<2, 1>(G, a, packed, NG, T, T, nwg, lds);
+    else if (PRO == 2) fused_go<2, 1>(G, a, packed, NG, T, T, nwg, lds);
+    else fused_go<4, 1>(G, a, packed, NG, T, T, nwg, lds);
   } else {
     if (PRO == 1) fused_go<1, 0>(G, a, packed, NG, T, T, nwg, lds);
-    else fused_go<2, 0>(G, a, packed, NG, T, T, nwg, lds);
+    else if (PRO == 2) fused_go<2, 0>(G, a, packed, NG, T, T, nwg, lds);
+    else fused_go<4, 0>(G, a, packed, NG, T, T, nwg, lds);
   }
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }

@@ -9,6 +9,7 @@
 namespace awq {
 
 constexpr int kRpMaxG = 8;
+constexpr int kRpMaxLds = 128 * 1024;      // dynamic LDS the fused variants may ask for (reduction scratch + prologue x)
 inline int rp_groups(int64_t N) { return (int)((N + 15) / 16); }
 
 // diagnostic only (tools/kbench rstamps): when set, workgroups write 100 MHz-clock stamps into this device buffer
@@ -73,10 +74,9 @@ __device__ __forceinline__ void rp_compute(const RpBlock& b, float4_t (&acc)[kRp
 }
 
 // Optional fusions for the decode harness (awq_aux.h: awq_aux_gemv_repacked_fused).
-//   PRO = chunks of 8 halves per thread (1 or 2): x is not read; x = rmsnorm(h + delta) * w is built in LDS by
-//         the whole workgroup while its weight loads are already in flight (h / delta / w are loaded BEFORE the
-//         weights, so the counted wait for them leaves the weight loads outstanding); workgroup 0 also stores
-//         h + delta.  Same arithmetic as add_rmsnorm_kernel: fp16 add, fp32 sum of squares, fp16(v * inv) * w.
+//   PRO = chunks of 8 halves per lane (1, 2 or 4; M * T * 16 <= 64 * PRO): x is not read; every wave builds
+//         x = rmsnorm(h + delta) * w for the columns of its own k-blocks (see the prologue in the kernel);
+//         workgroup 0 also stores h + delta.  Same arithmetic as add_rmsnorm_kernel: fp16 add, fp32 sum of squares, fp16(v * inv) * w.
 //   EPI = 1: column groups alternate gate / up (repacked from column-interleaved tensors); the epilogue writes
 //         act = fp16(silu(fp16 gate)) * fp16 up, [M, N / 2], instead of y.
 struct RpFuse {
@@ -122,68 +122,92 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
 
   if constexpr (T > 0) {
     RpBlock buf[T];
-    typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
-    constexpr int CH = PRO > 0 ? PRO : 1;
-    h8_t hv[CH], dv[CH], wv[CH];
-    int crow[CH], ccol[CH];
-    const int CK = K / 8;
-    if constexpr (PRO > 0) {                              // oldest loads of the wave: residual stream, delta, norm weight
+    if constexpr (PRO > 0) {
+      // Norm prologue.  Each wave owns the columns of its own k-blocks (T x 128) of every row: it loads h, delta
+      // and w for them, adds, and contributes per-row sums of squares; ONE workgroup barrier later every wave has
+      // the row sums, issues its weight loads, and normalises its own columns under their latency (wave-private
+      // LDS round trip into the MFMA fragment order, no second barrier).  Two rules found by measurement:
+      //  * the prologue loads must complete before any weight load is issued: with the weight stream of every
+      //    workgroup of the XCD queued in the L2 these few KB take ~3 us instead of ~0.4;
+      //  * no workgroup barrier after the weight loads: load ISSUE of the later waves is throttled by the saturated
+      //    memory pipeline, so a barrier there holds every wave until nearly all of the strip has arrived.
+      typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+      constexpr int CH = PRO;                                            // chunks of 8 halves per lane: M * T * 16 <= 64 * CH
+      constexpr int WC = T * 16;                                         // chunks per row in this wave's column range
+      half_t* x_lds = (half_t*)(red + (size_t)W * M * 16 * G) + (size_t)wave * M * (T * 128 + 8);   // wave-private [M][T * 128 (+8 pad)]
+      float* part = (float*)((half_t*)(red + (size_t)W * M * 16 * G) + (size_t)W * M * (T * 128 + 8));   // [M][W]
+      const int XS = T * 128 + 8;
+      const int col0 = kb_begin * 128;                                   // first column owned by this wave
+      h8_t hv[CH], dv[CH], wv[CH];
+      int crow[CH], ccol[CH];
+      bool cok[CH];
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        int c = (int)threadIdx.x + i * W * 64;
-        if (c >= M * CK) c = M * CK - 1;                  // clamped (its sum of squares and LDS store are masked below)
-        crow[i] = c / CK;
-        ccol[i] = c - crow[i] * CK;
-        hv[i] = *(const h8_t*)(fz.h + (size_t)crow[i] * ldx + ccol[i] * 8);
-        dv[i] = *(const h8_t*)(fz.delta + (size_t)crow[i] * ldx + ccol[i] * 8);
-        wv[i] = *(const h8_t*)(fz.w + ccol[i] * 8);
+        const int c = lane + i * 64;
+        crow[i] = c / WC;
+        ccol[i] = (c - crow[i] * WC) * 8;                                // column offset inside the wave's range
+        cok[i] = crow[i] < M && col0 + ccol[i] < K;
+        const int gr = cok[i] ? crow[i] : 0, gc = cok[i] ? col0 + ccol[i] : 0;     // clamped: loaded, then masked
+        hv[i] = *(const h8_t*)(fz.h + (size_t)gr * ldx + gc);
+        dv[i] = *(const h8_t*)(fz.delta + (size_t)gr * ldx + gc);
+        wv[i] = *(const h8_t*)(fz.w + gc);
       }
-    }
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const int kb = kb_begin + t < KB ? kb_begin + t : KB - 1;         // clamped: re-read, then weighted by x = 0
-      rp_load<G, NT, MT, PRO == 0>(buf[t], qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    RP_STAMP(1);
-    if constexpr (PRO > 0) {
-      half_t* x_lds = (half_t*)(red + (size_t)W * M * 16 * G);           // [M][K + 8] halves (rows 16 B apart in bank phase)
-      float* part = (float*)(x_lds + (size_t)M * (K + 8));               // [CH][W] per-wave sums of squares
-      const int XS = K + 8;
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
         hv[i] = hv[i] + dv[i];                                           // fp16 add, as the eager h = h + delta
         float ss = 0.f;
-        if ((int)threadIdx.x + i * W * 64 < M * CK) {
+        if (cok[i]) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) ss += (float)hv[i][e] * (float)hv[i][e];
         }
+        // a row's WC chunks sit in WC consecutive lanes (WC = 16, 32, 48 or 64): segmented sum over aligned groups of 16,
+        // then the group leaders of one row add up in LDS order below
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-        if (lane == 0) part[i * W + wave] = ss;
+        for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        if ((lane & 15) == 0) part[(wave * CH + i) * 4 + (lane >> 4)] = ss;   // [W][CH][4 sixteen-lane groups]
       }
       __syncthreads();
-      const int slots = CK / 64;                                         // wave-sized slots per row (K % 512 == 0)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int kb = kb_begin + t < KB ? kb_begin + t : KB - 1;         // clamped: re-read, then weighted by x = 0
+        rp_load<G, NT, MT, false>(buf[t], qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      RP_STAMP(1);
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        if ((int)threadIdx.x + i * W * 64 < M * CK) {
+        if (cok[i]) {
+          // sum of squares of row crow[i]: every (wave, chunk slot, 16-lane group) that belongs to that row, fixed order
           float tot = 0.f;
-          for (int sl = 0; sl < slots; ++sl) tot += part[crow[i] * slots + sl];     // fixed order: deterministic
+          for (int w2 = 0; w2 < W; ++w2)
+#pragma unroll
+            for (int i2 = 0; i2 < CH; ++i2) {
+              const float4_t p4 = *(const float4_t*)(part + (w2 * CH + i2) * 4);
+#pragma unroll
+              for (int g4 = 0; g4 < 4; ++g4)
+                if ((g4 * 16 + i2 * 64) / WC == crow[i]) tot += p4[g4];
+            }
           const float inv = __builtin_amdgcn_rsqf(tot / (float)K + fz.eps);
           h8_t o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)hv[i][e] * inv) * wv[i][e];
-          *(h8_t*)(x_lds + (size_t)crow[i] * XS + ccol[i] * 8) = o;
-          if (blockIdx.x == 0) *(h8_t*)(fz.h_out + (size_t)crow[i] * ldx + ccol[i] * 8) = hv[i];
+          *(h8_t*)(x_lds + (size_t)crow[i] * XS + ccol[i]) = o;
+          if (blockIdx.x == 0) *(h8_t*)(fz.h_out + (size_t)crow[i] * ldx + col0 + ccol[i]) = hv[i];
         }
       }
-      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) buf[t].xa[d][0] = *(const u32x4_t*)(x_lds + (size_t)xr[0] * XS + t * 128 + d * 32 + q * 8);
+    } else {
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        const int kb = kb_begin + t < KB ? kb_begin + t : KB - 1;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) buf[t].xa[d][0] = *(const u32x4_t*)(x_lds + (size_t)xr[0] * XS + kb * 128 + d * 32 + q * 8);
+        const int kb = kb_begin + t < KB ? kb_begin + t : KB - 1;         // clamped: re-read, then weighted by x = 0
+        rp_load<G, NT, MT, true>(buf[t], qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      RP_STAMP(1);
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -290,9 +314,15 @@ static void rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wav
   dim3 grid(nwg), block(W * 64);
 #define RP_GO(TT)                                                                                                                     \
   if constexpr ((PRO == 0 && EPI == 0) ? (rp_fits(W, MT, G, TT) && (MT == 1 || TT == 0 || TT == 4))                                     \
-                                       : (W == 16 && NT && MT == 1 && rp_fits_fused(G, TT, PRO, EPI)))                                   \
-    hipLaunchKernelGGL((gemv_repacked_kernel<G, TT, W, NT, MT, PRO, EPI>), grid, block, lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, \
-                       zs_r, a.bias, a.y, a.M, a.K, a.N, a.g, NG, per_wave, g_rp_stamp_buffer, fz)
+                                       : (W == 16 && NT && MT == 1 && rp_fits_fused(G, TT, PRO, EPI))) {                                 \
+    auto kern = gemv_repacked_kernel<G, TT, W, NT, MT, PRO, EPI>;                                                                       \
+    if (lds > 64 * 1024) {                       /* one workgroup per CU: opt in to more of its 160 KiB of LDS, once */                  \
+      static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kRpMaxLds);     \
+      (void)once;                                                                                                                       \
+    }                                                                                                                                   \
+    hipLaunchKernelGGL(kern, grid, block, lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r, a.bias, a.y, a.M, a.K, a.N, a.g, NG,   \
+                       per_wave, g_rp_stamp_buffer, fz);                                                                                \
+  }
   switch (T) {
     case 1: RP_GO(1); break;
     case 2: RP_GO(2); break;

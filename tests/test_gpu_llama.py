@@ -66,33 +66,32 @@ def test_tiny_llama_decode_matches_fp32_reference_and_graph_replay():
                       num_key_value_heads=2, vocab_size=512, max_position_embeddings=64)
     quant = AWQConfig(4, 128, True)
     with torch.device(DEV):
-        model = LlamaForCausalLM(cfg, quant, max_batch=4, max_seq=32)
+        model = LlamaForCausalLM(cfg, quant, max_batch=20, max_seq=32)
     model.init_synthetic_(seed=3)
     W = []
     for layer in model.layers:
         W.append({name: ops.awq_dequantize(lin.qweight, lin.scales, lin.qzeros).float()
                   for name, lin in (("qkv", layer.qkv_proj), ("o", layer.o_proj), ("gate_up", layer.gate_up_proj), ("down", layer.down_proj))})
-    B = 3
-    kc = [torch.zeros(B, l.num_kv_heads, 32, cfg.head_dim, device=DEV) for l in model.layers]
-    vc = [torch.zeros(B, l.num_kv_heads, 32, cfg.head_dim, device=DEV) for l in model.layers]
-    tokens = torch.tensor([5, 17, 300], device=DEV)
-    pos = torch.tensor([0, 0, 0], device=DEV)
-    with torch.no_grad():
-        for fused in (False, True):              # plain torch neighbours, then the fused aux kernels
-            model.fused_aux = fused
-            for layer in model.layers:
-                layer.k_cache.zero_(); layer.v_cache.zero_()
-            for t_ in kc + vc:
-                t_.zero_()
-            tokens = torch.tensor([5, 17, 300], device=DEV)
-            pos = torch.tensor([0, 0, 0], device=DEV)
-            for step in range(4):
-                got = model.logits(tokens, pos).float()
-                want = _ref_step(model, W, tokens, pos, kc, vc)
-                scale = want.abs().max().item()
-                assert (got - want).abs().max().item() <= 2e-2 * scale + 2e-2, f"fused={fused} step {step}"
-                tokens = want.argmax(-1)
-                pos = pos + 1
+    # batch 3: norm prologue + SiLU-mul epilogue inside the GEMVs; 6: separate norm launch, fused epilogue; 20: all separate
+    for B in (3, 6, 20):
+        kc = [torch.zeros(B, l.num_kv_heads, 32, cfg.head_dim, device=DEV) for l in model.layers]
+        vc = [torch.zeros(B, l.num_kv_heads, 32, cfg.head_dim, device=DEV) for l in model.layers]
+        with torch.no_grad():
+            for fused in (False, True):              # plain torch neighbours, then the fused aux kernels
+                model.fused_aux = fused
+                for layer in model.layers:
+                    layer.k_cache.zero_(); layer.v_cache.zero_()
+                for t_ in kc + vc:
+                    t_.zero_()
+                tokens = (torch.arange(B, device=DEV) * 37 + 5) % cfg.vocab_size
+                pos = torch.arange(B, device=DEV) % 3          # ragged start positions (cache slots below are zeros)
+                for step in range(4):
+                    got = model.logits(tokens, pos).float()
+                    want = _ref_step(model, W, tokens, pos, kc, vc)
+                    scale = want.abs().max().item()
+                    assert (got - want).abs().max().item() <= 2e-2 * scale + 2e-2, f"B={B} fused={fused} step {step}"
+                    tokens = want.argmax(-1)
+                    pos = pos + 1
 
     # graph replay produces the same token stream as eager stepping
     for layer in model.layers:

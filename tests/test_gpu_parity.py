@@ -189,7 +189,8 @@ def test_gemv_repacked_fused_vs_oracle(ops, M):
     from sglang_awq_amd import aux_ops
 
     eps = 1e-5
-    for (K, N, g) in [(512, 64, 128), (1024, 1056 * 2, 128), (4096, 12288, 128), (4096, 22016, 128), (2048, 4096, 2048)]:
+    for (K, N, g) in [(384, 96, 128), (512, 64, 128), (1024, 1056 * 2, 128), (4096, 12288, 128), (4096, 22016, 128), (2048, 4096, 2048),
+                      (8192, 1024, 128)]:
         qw, s, qz = synth.make_awq_weights(K, N, g, "f16", "A", seed=M * 31 + K + N)
         h = synth.make_activations(M, K, "f16", "A", seed=M + K + 3)
         delta = synth.make_activations(M, K, "f16", "A", seed=M + K + 4)
@@ -211,14 +212,16 @@ def test_gemv_repacked_fused_vs_oracle(ops, M):
 
         # 1. norm prologue only
         r = aux_ops.gemv_repacked_fused(packed, K, N, g, norm=(dev[0], dev[1], dev[2], eps))
-        if M * K <= 16384 and K % 512 == 0:
-            assert r is not None, f"no fused kernel for M={M} K={K} N={N}"
-            y, h_out = r
-            assert np.array_equal(to_np(h_out), v)
-            _, exact = c_oracle.gemm(xn, qw, s, qz, want_exact=True)
-            assert_gemm_close(to_np(y), exact, "f16", atol=2e-3, what=f"norm-fused M={M} K={K} N={N}")
-        else:
-            assert r is None
+        assert r is not None, f"no fused kernel for M={M} K={K} N={N}"
+        y, h_out = r
+        assert np.array_equal(to_np(h_out), v)
+        _, exact = c_oracle.gemm(xn, qw, s, qz, want_exact=True)
+        got = to_np(y).astype(np.float64)
+        err = np.abs(got - exact)
+        assert np.all(err <= 0.5 * ulp(exact, "f16") + 2e-3), f"norm-fused M={M} K={K} N={N}: worst {err.max():.3e}"
+        # x itself can differ from the numpy rebuild by an fp16 ulp in a few elements (v_rsq_f32 vs exact 1 / sqrt), so
+        # "equals the correctly rounded sum of the rebuilt x" holds for most outputs, not 98 % as for a given x
+        assert float((got != exact.astype(np.float16).astype(np.float64)).mean()) < 0.15
         # 2. SiLU-mul epilogue only (x given)
         x = synth.make_activations(M, K, "f16", "A", seed=M + K + 6)
         r = aux_ops.gemv_repacked_fused(packed_il, K, N, g, x=to_torch(x, DEV), silu_mul=True)
@@ -232,14 +235,13 @@ def test_gemv_repacked_fused_vs_oracle(ops, M):
         assert float((got != want).mean()) < 0.05
         # 3. both
         r = aux_ops.gemv_repacked_fused(packed_il, K, N, g, norm=(dev[0], dev[1], dev[2], eps), silu_mul=True)
-        if M * K <= 16384 and K % 512 == 0:
-            assert r is not None
-            _, exact = c_oracle.gemm(xn, qw, s, qz, want_exact=True)
-            want = silu_mul(exact).astype(np.float64)
-            got = to_np(r[0]).astype(np.float64)
-            tol = 2.0 * ulp(want, "f16") + 4e-3 * (1.0 + np.abs(exact[:, N // 2:]))
-            assert np.all(np.abs(got - want) <= tol), f"norm+silu M={M} K={K} N={N}: worst {np.abs(got - want).max():.3e}"
-            assert np.array_equal(to_np(r[1]), v)
+        assert r is not None
+        _, exact = c_oracle.gemm(xn, qw, s, qz, want_exact=True)
+        want = silu_mul(exact).astype(np.float64)
+        got = to_np(r[0]).astype(np.float64)
+        tol = 2.0 * ulp(want, "f16") + 4e-3 * (1.0 + np.abs(exact[:, N // 2:]))
+        assert np.all(np.abs(got - want) <= tol), f"norm+silu M={M} K={K} N={N}: worst {np.abs(got - want).max():.3e}"
+        assert np.array_equal(to_np(r[1]), v)
 
 
 def test_gemm_repacked_tiled_vs_oracle(ops):
@@ -454,3 +456,16 @@ def test_awq_linear_method_apply_matches_oracle(ops):
         tol = 1.01 if mode == "fused" else 2.02
         # ... and the bias add rounds once more, which can move the result by one further ulp of its own
         assert np.all(np.abs(got - want) <= tol * (ulp(want, "f16") + ulp(pre, "f16"))), mode
+
+
+def test_gemv_repacked_fused_refuses_what_it_cannot_run(ops):
+    """Shapes without a fused instantiation return None (AWQ_ERR_BAD_VARIANT at the C boundary) so callers run the
+    separate ops: 16 rows of K = 4096 (prologue registers / LDS), K = 16384 (more than 4 k-blocks per wave)."""
+    from sglang_awq_amd import aux_ops
+
+    for (M, K, N) in [(16, 4096, 512), (1, 16384, 256)]:
+        qw, s, qz = synth.make_awq_weights(K, N, 128, "f16", "A", seed=5)
+        packed = ops.awq_repack(*_dev(qw, s, qz))
+        h = torch.zeros(M, K, dtype=torch.float16, device=DEV)
+        w = torch.ones(K, dtype=torch.float16, device=DEV)
+        assert aux_ops.gemv_repacked_fused(packed, K, N, 128, norm=(h, h.clone(), w, 1e-5)) is None

@@ -17,6 +17,7 @@
 #include <string>
 #include <vector>
 
+#include "../include/awq_aux.h"
 #include "../include/awq_hip.h"
 
 #define CK(x)                                                                      \
@@ -290,11 +291,12 @@ static int cmd_stamps(int argc, char** argv) {
 
 // decode GEMV on the repacked (MFMA-fragment-major) layout
 static int cmd_rgemm(int argc, char** argv) {
-  if (argc < 6) { fprintf(stderr, "usage: kbench rgemm M K N g [sets] [iters] [graph]\n"); return 2; }
+  if (argc < 6) { fprintf(stderr, "usage: kbench rgemm M K N g [sets] [iters] [graph] [fuse: 1 norm prologue, 2 silu-mul epilogue, 3 both]\n"); return 2; }
   const int M = atoi(argv[2]), K = atoi(argv[3]), N = atoi(argv[4]), g = atoi(argv[5]);
   const int sets = argc > 6 ? atoi(argv[6]) : 16;
   const int iters = argc > 7 ? atoi(argv[7]) : 400;
   const int use_graph = argc > 8 ? atoi(argv[8]) : 1;
+  const int fuse = argc > 9 ? atoi(argv[9]) : 0;
   const size_t pbytes = awq_repacked_bytes(K, N, g, AWQ_DTYPE_F16);
   if (!pbytes) { fprintf(stderr, "shape not supported by the repacked path\n"); return 1; }
   hipStream_t st; CK(hipStreamCreate(&st));
@@ -312,9 +314,15 @@ static int cmd_rgemm(int argc, char** argv) {
   void *x, *y;
   CK(hipMalloc(&x, (size_t)M * K * 2)); fill_scales(x, (size_t)M * K, AWQ_DTYPE_F16, -1.f, 1.f);
   CK(hipMalloc(&y, (size_t)M * N * 2));
+  void *delta, *nw, *hout;
+  CK(hipMalloc(&delta, (size_t)M * K * 2)); fill_scales(delta, (size_t)M * K, AWQ_DTYPE_F16, -1.f, 1.f);
+  CK(hipMalloc(&nw, (size_t)K * 2)); fill_scales(nw, (size_t)K, AWQ_DTYPE_F16, 0.5f, 1.5f);
+  CK(hipMalloc(&hout, (size_t)M * K * 2));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto launch = [&](int i) {
-    int rc = awq_gemm_repacked(x, K, packed[i % sets], nullptr, y, M, K, N, g, AWQ_DTYPE_F16, st);
+    int rc = fuse ? awq_aux_gemv_repacked_fused(x, K, packed[i % sets], y, M, K, N, g, AWQ_DTYPE_F16, (fuse & 1) ? x : nullptr, delta, nw, hout,
+                                                1e-5f, (fuse & 2) ? 1 : 0, st)
+                  : awq_gemm_repacked(x, K, packed[i % sets], nullptr, y, M, K, N, g, AWQ_DTYPE_F16, st);
     if (rc) { fprintf(stderr, "awq_gemm_repacked: %s\n", awq_hip_status_string(rc)); exit(1); }
   };
   for (int i = 0; i < 2 * sets; ++i) launch(i);
@@ -345,7 +353,7 @@ static int cmd_rgemm(int argc, char** argv) {
   }
   const double us = ms * 1e3;
   const double bytes = (double)K * N / 2 + (double)(K / g) * N / 2 + (double)(K / g) * N * 2 + (double)M * K * 2 + (double)M * N * 2;
-  printf("rgemm M=%d K=%d N=%d g=%d sets=%d graph=%d : %9.3f us  %8.1f GB/s (algorithmic)  %8.2f TFLOP/s\n", M, K, N, g, sets, use_graph, us,
+  printf("rgemm M=%d K=%d N=%d g=%d sets=%d graph=%d fuse=%d : %9.3f us  %8.1f GB/s (algorithmic)  %8.2f TFLOP/s\n", M, K, N, g, sets, use_graph, fuse, us,
          bytes / us / 1e3, 2.0 * M * K * N / us / 1e6);
   return 0;
 }
@@ -353,9 +361,10 @@ static int cmd_rgemm(int argc, char** argv) {
 extern "C" void awq_debug_set_stamp_buffer(void* p);   // diagnostic hook of libawq_hip.so (not in the public header)
 
 static int cmd_rstamps(int argc, char** argv) {
-  if (argc < 6) { fprintf(stderr, "usage: kbench rstamps M K N g [sets]\n"); return 2; }
+  if (argc < 6) { fprintf(stderr, "usage: kbench rstamps M K N g [sets] [fuse]\n"); return 2; }
   const int M = atoi(argv[2]), K = atoi(argv[3]), N = atoi(argv[4]), g = atoi(argv[5]);
   const int sets = argc > 6 ? atoi(argv[6]) : 16;
+  const int fuse = argc > 7 ? atoi(argv[7]) : 0;
   const size_t pbytes = awq_repacked_bytes(K, N, g, AWQ_DTYPE_F16);
   hipStream_t st; CK(hipStreamCreate(&st));
   std::vector<void*> packed(sets);
@@ -369,13 +378,20 @@ static int cmd_rstamps(int argc, char** argv) {
   void *x, *y; unsigned long long* dbg;
   CK(hipMalloc(&x, (size_t)M * K * 2)); fill_scales(x, (size_t)M * K, AWQ_DTYPE_F16, -1.f, 1.f);
   CK(hipMalloc(&y, (size_t)M * N * 2));
+  void *delta, *nw, *hout;
+  CK(hipMalloc(&delta, (size_t)M * K * 2)); fill_scales(delta, (size_t)M * K, AWQ_DTYPE_F16, -1.f, 1.f);
+  CK(hipMalloc(&nw, (size_t)K * 2)); fill_scales(nw, (size_t)K, AWQ_DTYPE_F16, 0.5f, 1.5f);
+  CK(hipMalloc(&hout, (size_t)M * K * 2));
   const int max_wg = 4096;
   CK(hipMalloc(&dbg, (size_t)max_wg * 64));
   awq_debug_set_stamp_buffer(dbg);
   std::vector<unsigned long long> h((size_t)max_wg * 8);
   for (int rep = 0; rep < 2 * sets + 3; ++rep) {
     CK(hipMemsetAsync(dbg, 0, (size_t)max_wg * 64, st));
-    if (awq_gemm_repacked(x, K, packed[rep % sets], nullptr, y, M, K, N, g, AWQ_DTYPE_F16, st)) return 1;
+    const int rc = fuse ? awq_aux_gemv_repacked_fused(x, K, packed[rep % sets], y, M, K, N, g, AWQ_DTYPE_F16, (fuse & 1) ? x : nullptr, delta,
+                                                      nw, hout, 1e-5f, (fuse & 2) ? 1 : 0, st)
+                        : awq_gemm_repacked(x, K, packed[rep % sets], nullptr, y, M, K, N, g, AWQ_DTYPE_F16, st);
+    if (rc) { fprintf(stderr, "launch failed: %s\n", awq_hip_status_string(rc)); return 1; }
     CK(hipStreamSynchronize(st));
   }
   awq_debug_set_stamp_buffer(nullptr);
