@@ -23,7 +23,7 @@ int awq_aux_rope_kv(void* qkv, const int64_t* pos, const float* cos_table, const
 
 /* RoPE + KV-cache write + attention of ONE new token per sequence, in one launch (models/llama.py:188-199: rotary_emb, then
  * RadixAttention decode).  qkv[B, (Hq + 2 Hkv) D] is read only; k, v of the token are stored at pos[b] (which must be < S) and
- * out[B, Hq D] = softmax(scale q K^T) V over cache slots 0..pos[b].  D in {64, 128}, Hq % Hkv == 0, S <= 12288. */
+ * out[B, Hq D] = softmax(scale q K^T) V over cache slots 0..pos[b].  D in {64, 128}, Hq % Hkv == 0. */
 int awq_aux_decode_attention(const void* qkv, const int64_t* pos, const float* cos_table, const float* sin_table, void* k_cache,
                              void* v_cache, void* out, int64_t B, int64_t Hq, int64_t Hkv, int64_t D, int64_t S, float scale,
                              void* stream);

@@ -80,30 +80,43 @@ __global__ void rope_kv_kernel(half_t* __restrict__ qkv, const int64_t* __restri
 // KV-cache write of the new token folded in (what rope_kv_kernel + an SDPA launch did in two).  The new
 // token's k / v come straight from qkv (every workgroup of a GQA group rotates its own copy; the group's first
 // head stores them), so no workgroup reads what another one writes in the same launch.
-//   pass 1: scores s_j = scale * q . k_j (LP = D / 8 lanes x 16 B per cached position), kept in LDS
-//   pass 2: softmax weights in place, fp32; pass 3: out = sum_j p_j v_j / sum_j p_j, reduced over the
-//   256 / LP position groups through LDS.
+// Latency-bound at decode sizes (a few hundred KB per workgroup), so the structure minimises dependent round
+// trips: the first block of K AND V rows is requested at kernel entry, before pos[b] is known (the cache is
+// allocated to S rows, rows past pos are masked later); K and V of a position travel together and feed an
+// online softmax kept per 16-lane position group (LP = D / 8 lanes x 16 B per cached row, 256 / LP groups,
+// 4 positions per group in flight, the next block prefetched while the current one is reduced); the groups are
+// merged once through LDS.  No per-position storage: any context length.
 template <int D>
 __global__ __launch_bounds__(256) void decode_attention_kernel(const half_t* __restrict__ qkv, const int64_t* __restrict__ pos,
                                                                const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                                half_t* __restrict__ kc, half_t* __restrict__ vc,
                                                                half_t* __restrict__ out, int Hq, int Hkv, int S, float scale) {
-  constexpr int LP = D / 8, NPG = 256 / LP, HALF = D / 2;
-  extern __shared__ __attribute__((aligned(16))) float dyn[];       // scores [S]
+  constexpr int LP = D / 8, NPG = 256 / LP, HALF = D / 2, U = 4;
   __shared__ float q_s[D];
   __shared__ __attribute__((aligned(16))) half_t knew_s[D];
   __shared__ __attribute__((aligned(16))) half_t vnew_s[D];
-  __shared__ float scratch[8];
+  __shared__ float m_s[NPG], l_s[NPG];
   __shared__ float part[NPG][D];
 
   const int b = blockIdx.y, h = blockIdx.x, t = threadIdx.x;
   const int rep = Hq / Hkv, kvh = h / rep;
   const bool owner = (h % rep) == 0;
-  const int p = (int)pos[b];                                        // cached positions 0 .. p-1, the new token is p
-  const half_t* row = qkv + (size_t)b * (Hq + 2 * Hkv) * D;
+  const int lp = t % LP, pg = t / LP;
   half_t* kbase = kc + ((size_t)b * Hkv + kvh) * (size_t)S * D;
   half_t* vbase = vc + ((size_t)b * Hkv + kvh) * (size_t)S * D;
 
+  // block 0 of K / V: addresses do not depend on pos (rows < S exist; what lies past pos is masked below)
+  half8v kv[U], vv[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int j = pg + u * NPG;
+    const int jc = j < S ? j : S - 1;
+    kv[u] = *(const half8v*)(kbase + (size_t)jc * D + lp * 8);
+    vv[u] = *(const half8v*)(vbase + (size_t)jc * D + lp * 8);
+  }
+
+  const int p = (int)pos[b];                                        // cached positions 0 .. p-1, the new token is p
+  const half_t* row = qkv + (size_t)b * (Hq + 2 * Hkv) * D;
   if (t < HALF) {                                                    // q: rotate, round to fp16 as the unfused path does, pre-scale
     const float c = cos_t[(size_t)p * HALF + t], sn = sin_t[(size_t)p * HALF + t];
     const float x1 = (float)row[(size_t)h * D + t], x2 = (float)row[(size_t)h * D + t + HALF];
@@ -134,83 +147,78 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const half_t* __r
   }
   __syncthreads();
 
-  const int lp = t % LP, pg = t / LP;
   float qf[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) qf[e] = q_s[lp * 8 + e];
+  const half8v knew = *(const half8v*)(knew_s + lp * 8), vnew = *(const half8v*)(vnew_s + lp * 8);
 
-  // pass 1: 4 positions per thread group in flight
-  float mx = -INFINITY;
-  for (int j0 = pg; j0 <= p; j0 += 4 * NPG) {
-    half8v kv[4];
+  float m = -INFINITY, l = 0.f;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int j0 = pg; j0 <= p; j0 += U * NPG) {
+    half8v kn[U], vn[U];                                             // next block, requested before this one is reduced
+    const bool more = j0 + U * NPG <= p;
+    if (more) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int j = j0 + u * NPG;
-      const int jc = j < p ? j : (p > 0 ? p - 1 : 0);               // clamped: the load is unconditional, the result is not used
-      kv[u] = *(const half8v*)(kbase + (size_t)jc * D + lp * 8);
+      for (int u = 0; u < U; ++u) {
+        const int j = j0 + (U + u) * NPG;
+        const int jc = j < p ? j : (p > 0 ? p - 1 : 0);
+        kn[u] = *(const half8v*)(kbase + (size_t)jc * D + lp * 8);
+        vn[u] = *(const half8v*)(vbase + (size_t)jc * D + lp * 8);
+      }
     }
+    float sc[U];
+    float bm = m;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int j = j0 + u * NPG;
-      if (j > p) break;
-      const half8v k8 = j == p ? *(const half8v*)(knew_s + lp * 8) : kv[u];
+      const half8v k8 = j == p ? knew : kv[u];
       float d = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) d += qf[e] * (float)k8[e];
 #pragma unroll
       for (int o = LP / 2; o > 0; o >>= 1) d += __shfl_xor(d, o);
-      if (lp == 0) dyn[j] = d;
-      mx = fmaxf(mx, d);
+      sc[u] = j <= p ? d : -INFINITY;
+      bm = fmaxf(bm, sc[u]);
     }
-  }
+    const float corr = __expf(m - bm);                               // first block: exp(-inf) = 0 (bm is finite: j0 <= p)
+    l *= corr;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  if ((t & 63) == 0) scratch[t >> 6] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
-  __syncthreads();
-
-  // pass 2: weights
-  float sum = 0.f;
-  for (int j = t; j <= p; j += 256) {
-    const float e = __expf(dyn[j] - mx);
-    dyn[j] = e;
-    sum += e;
-  }
+    for (int e = 0; e < 8; ++e) acc[e] *= corr;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-  if ((t & 63) == 0) scratch[4 + (t >> 6)] = sum;
-  __syncthreads();
-  const float inv = 1.f / (scratch[4] + scratch[5] + scratch[6] + scratch[7]);
-
-  // pass 3: weighted sum of v
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int j0 = pg; j0 <= p; j0 += 4 * NPG) {
-    half8v vv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int j = j0 + u * NPG;
-      const int jc = j < p ? j : (p > 0 ? p - 1 : 0);
-      vv[u] = *(const half8v*)(vbase + (size_t)jc * D + lp * 8);
+      if (j <= p) {                                                  // rows past pos may hold anything (even NaN): never touch them
+        const half8v v8 = j == p ? vnew : vv[u];
+        const float w = __expf(sc[u] - bm);
+        l += w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += w * (float)v8[e];
+      }
     }
+    m = bm;
+    if (more) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int j = j0 + u * NPG;
-      if (j > p) break;
-      const half8v v8 = j == p ? *(const half8v*)(vnew_s + lp * 8) : vv[u];
-      const float w = dyn[j];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += w * (float)v8[e];
+      for (int u = 0; u < U; ++u) { kv[u] = kn[u]; vv[u] = vn[u]; }
     }
   }
+
+  // merge the position groups (a group that saw no position has m = -inf, l = 0)
+  if (lp == 0) { m_s[pg] = m; l_s[pg] = l; }
 #pragma unroll
   for (int e = 0; e < 8; ++e) part[pg][lp * 8 + e] = acc[e];
   __syncthreads();
   if (t < D) {
-    float o = 0.f;
+    float mx = m_s[0];
 #pragma unroll
-    for (int g = 0; g < NPG; ++g) o += part[g][t];
-    out[((size_t)b * Hq + h) * D + t] = (half_t)(o * inv);
+    for (int g = 1; g < NPG; ++g) mx = fmaxf(mx, m_s[g]);
+    float o = 0.f, lt = 0.f;
+#pragma unroll
+    for (int g = 0; g < NPG; ++g) {
+      const float f = __expf(m_s[g] - mx);
+      o += part[g][t] * f;
+      lt += l_s[g] * f;
+    }
+    out[((size_t)b * Hq + h) * D + t] = (half_t)(o / lt);
   }
 }
 
@@ -254,9 +262,9 @@ int awq_aux_rope_kv(void* qkv, const int64_t* pos, const float* cos_t, const flo
 int awq_aux_decode_attention(const void* qkv, const int64_t* pos, const float* cos_t, const float* sin_t, void* k_cache, void* v_cache,
                              void* out, int64_t B, int64_t Hq, int64_t Hkv, int64_t D, int64_t S, float scale, void* stream) {
   if (!qkv || !pos || !cos_t || !sin_t || !k_cache || !v_cache || !out) return AWQ_ERR_NULL_POINTER;
-  if (B <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || (D != 64 && D != 128) || S <= 0 || S > 12288) return AWQ_ERR_BAD_SHAPE;
+  if (B <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || (D != 64 && D != 128) || S <= 0) return AWQ_ERR_BAD_SHAPE;
   const dim3 grid((unsigned)Hq, (unsigned)B), block(256);
-  const size_t lds = (size_t)S * sizeof(float);
+  const size_t lds = 0;
 #define AWQ_ATTN_GO(DD)                                                                                                          \
   hipLaunchKernelGGL(awq::decode_attention_kernel<DD>, grid, block, lds, (hipStream_t)stream, (const awq::half_t*)qkv, pos, cos_t, \
                      sin_t, (awq::half_t*)k_cache, (awq::half_t*)v_cache, (awq::half_t*)out, (int)Hq, (int)Hkv, (int)S, scale)
