@@ -37,8 +37,18 @@ int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed) {
     PRO = per_lane <= 1 ? 1 : per_lane <= 2 ? 2 : per_lane <= 4 ? 4 : 0;
     if (!PRO) return AWQ_ERR_BAD_VARIANT;
   }
-  if (!rp_fits_fused(G, T, PRO, a.silu_mul)) return AWQ_ERR_BAD_VARIANT;
   size_t lds = (size_t)W * a.M * 16 * G * sizeof(float);
+  if (!norm) {                                                               // SiLU-mul epilogue only: x through wave-private LDS when it fits
+    const int per_lane = (a.M * T * 16 + 63) / 64;
+    const size_t xl_lds = lds + (size_t)W * a.M * (T * 128 + 8) * 2;
+    if (rp_fits_xl(G, T) && per_lane <= 4 && xl_lds <= 64 * 1024) {
+      if (per_lane <= 1) fused_go<-1, 1>(G, a, packed, NG, T, T, nwg, xl_lds);
+      else if (per_lane <= 2) fused_go<-2, 1>(G, a, packed, NG, T, T, nwg, xl_lds);
+      else fused_go<-4, 1>(G, a, packed, NG, T, T, nwg, xl_lds);
+      return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+    }
+  }
+  if (!rp_fits_fused(G, T, PRO, a.silu_mul)) return AWQ_ERR_BAD_VARIANT;
   if (norm) lds += (size_t)W * a.M * (T * 128 + 8) * 2 + (size_t)W * PRO * 4 * sizeof(float);
   if (lds > (size_t)kRpMaxLds) return AWQ_ERR_BAD_VARIANT;
   if (a.silu_mul) {

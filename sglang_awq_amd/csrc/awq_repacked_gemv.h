@@ -77,6 +77,8 @@ __device__ __forceinline__ void rp_compute(const RpBlock& b, float4_t (&acc)[kRp
 //   PRO = chunks of 8 halves per lane (1, 2 or 4; M * T * 16 <= 64 * PRO): x is not read; every wave builds
 //         x = rmsnorm(h + delta) * w for the columns of its own k-blocks (see the prologue in the kernel);
 //         workgroup 0 also stores h + delta.  Same arithmetic as add_rmsnorm_kernel: fp16 add, fp32 sum of squares, fp16(v * inv) * w.
+//   PRO < 0: no norm, x itself staged compactly through wave-private LDS (-PRO chunks per lane); chosen by the plain
+//         launcher where it lets a straight-line depth fit that would otherwise spill (see the kernel).
 //   EPI = 1: column groups alternate gate / up (repacked from column-interleaved tensors); the epilogue writes
 //         act = fp16(silu(fp16 gate)) * fp16 up, [M, N / 2], instead of y.
 struct RpFuse {
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
                                                                           const void* __restrict__ bias, void* __restrict__ y,
                                                                           int M, int K, int N, int g, int NG, int per_wave,
                                                                           unsigned long long* __restrict__ dbg, RpFuse fz) {
-  static_assert(PRO == 0 || (T > 0 && MT == 1), "the norm prologue exists for the straight-line single-tile variants");
+  static_assert(PRO == 0 || (T > 0 && MT == 1), "x through LDS (norm prologue or not) exists for the straight-line single-tile variants");
   extern __shared__ __attribute__((aligned(16))) float red[];    // [W][M][16 G]
 #define RP_STAMP(slot) do { if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   RP_STAMP(0);
@@ -122,6 +124,9 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
 
   if constexpr (T > 0) {
     RpBlock buf[T];
+    // PRO != 0: this wave's x columns live in wave-private LDS, [M][T * 128 (+8 halves: rows 16 B apart in bank phase)]
+    half_t* const x_lds = (half_t*)(red + (size_t)W * M * 16 * G) + (size_t)wave * M * (T * 128 + 8);
+    constexpr int XS = T * 128 + 8;
     if constexpr (PRO > 0) {
       // Norm prologue.  Each wave owns the columns of its own k-blocks (T x 128) of every row: it loads h, delta
       // and w for them, adds, and contributes per-row sums of squares; ONE workgroup barrier later every wave has
@@ -134,9 +139,7 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
       typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
       constexpr int CH = PRO;                                            // chunks of 8 halves per lane: M * T * 16 <= 64 * CH
       constexpr int WC = T * 16;                                         // chunks per row in this wave's column range
-      half_t* x_lds = (half_t*)(red + (size_t)W * M * 16 * G) + (size_t)wave * M * (T * 128 + 8);   // wave-private [M][T * 128 (+8 pad)]
       float* part = (float*)((half_t*)(red + (size_t)W * M * 16 * G) + (size_t)W * M * (T * 128 + 8));   // [M][W]
-      const int XS = T * 128 + 8;
       const int col0 = kb_begin * 128;                                   // first column owned by this wave
       h8_t hv[CH], dv[CH], wv[CH];
       int crow[CH], ccol[CH];
@@ -196,10 +199,35 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
           if (blockIdx.x == 0) *(h8_t*)(fz.h_out + (size_t)crow[i] * ldx + col0 + ccol[i]) = hv[i];
         }
       }
+    } else if constexpr (PRO < 0) {
+      // x through wave-private LDS, no norm: the MFMA A layout replicates a row over 16 lanes (16 registers of x per
+      // k-block whatever M is); loaded compactly instead (CH dwordx4 per lane for the wave's own M x T x 128 halves,
+      // requested BEFORE its weights so they return first) and re-read per k-block as fragments, a narrow strip holds
+      // 5 G registers per k-block instead of 5 G + 16 — deep enough straight-line code for K = 11008 at 16 waves.
+      typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+      constexpr int CH = -PRO, WC = T * 16;
+      const int col0 = kb_begin * 128;
+      h8_t xv[CH];
+      int crow[CH], ccol[CH];
+      bool cok[CH];
 #pragma unroll
-      for (int t = 0; t < T; ++t)
+      for (int i = 0; i < CH; ++i) {
+        const int c = lane + i * 64;
+        crow[i] = c / WC;
+        ccol[i] = (c - crow[i] * WC) * 8;
+        cok[i] = crow[i] < M && col0 + ccol[i] < K;
+        xv[i] = *(const h8_t*)((const half_t*)x + (cok[i] ? (size_t)crow[i] * ldx + col0 + ccol[i] : 0));
+      }
 #pragma unroll
-        for (int d = 0; d < 4; ++d) buf[t].xa[d][0] = *(const u32x4_t*)(x_lds + (size_t)xr[0] * XS + t * 128 + d * 32 + q * 8);
+      for (int t = 0; t < T; ++t) {
+        const int kb = kb_begin + t < KB ? kb_begin + t : KB - 1;         // clamped: re-read, then weighted by x = 0
+        rp_load<G, NT, MT, false>(buf[t], qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      RP_STAMP(1);
+#pragma unroll
+      for (int i = 0; i < CH; ++i)
+        if (cok[i]) *(h8_t*)(x_lds + (size_t)crow[i] * XS + ccol[i]) = xv[i];
     } else {
 #pragma unroll
       for (int t = 0; t < T; ++t) {
@@ -211,6 +239,10 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
+      if constexpr (PRO != 0) {                            // fragments of this k-block only: 16 registers live at a time
+#pragma unroll
+        for (int d = 0; d < 4; ++d) buf[t].xa[d][0] = *(const u32x4_t*)(x_lds + (size_t)xr[0] * XS + t * 128 + d * 32 + q * 8);
+      }
       if (kb_begin + t >= KB) {
 #pragma unroll
         for (int d = 0; d < 4; ++d)
@@ -302,9 +334,12 @@ constexpr bool rp_fits(int W, int MT, int G, int T) {
 // plain kernel (tools/rp_resources.py lists them too).
 constexpr bool rp_fits_fused(int G, int T, int PRO, int EPI) {
   if (T < 1 || T > 4 || (EPI && (G & 1))) return false;
-  if (PRO == 2 && G == 8 && T == 2) return false;                  // 28 B of scratch
+  if (PRO >= 2 && G == 8 && T == 2) return false;                  // a few bytes of scratch
   return rp_fits(16, 1, G, T);
 }
+
+// x staged through wave-private LDS (PRO < 0), 16 waves: T k-blocks of 5 G registers each (tools/rp_resources.py)
+constexpr bool rp_fits_xl(int G, int T) { return T >= 1 && T <= 8 && G * T <= 16; }
 
 template <int G, int W, bool NT, int MT, int PRO, int EPI>
 static void rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wave, int T, int nwg, size_t lds) {
@@ -313,8 +348,9 @@ static void rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wav
   const RpFuse fz = {(const half_t*)a.norm_h, (const half_t*)a.norm_delta, (const half_t*)a.norm_w, (half_t*)a.norm_h_out, a.norm_eps};
   dim3 grid(nwg), block(W * 64);
 #define RP_GO(TT)                                                                                                                     \
-  if constexpr ((PRO == 0 && EPI == 0) ? (rp_fits(W, MT, G, TT) && (MT == 1 || TT == 0 || TT == 4))                                     \
-                                       : (W == 16 && NT && MT == 1 && rp_fits_fused(G, TT, PRO, EPI))) {                                 \
+  if constexpr ((PRO == 0 && EPI == 0) ? (TT <= 6 && rp_fits(W, MT, G, TT) && (MT == 1 || TT == 0 || TT == 4))                           \
+                : (PRO < 0)            ? (W == 16 && NT && MT == 1 && !(EPI && (G & 1)) && rp_fits_xl(G, TT))                            \
+                                       : (TT <= 6 && W == 16 && NT && MT == 1 && rp_fits_fused(G, TT, PRO, EPI))) {                      \
     auto kern = gemv_repacked_kernel<G, TT, W, NT, MT, PRO, EPI>;                                                                       \
     if (lds > 64 * 1024) {                       /* one workgroup per CU: opt in to more of its 160 KiB of LDS, once */                  \
       static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kRpMaxLds);     \
@@ -330,6 +366,8 @@ static void rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wav
     case 4: RP_GO(4); break;
     case 5: RP_GO(5); break;
     case 6: RP_GO(6); break;
+    case 7: RP_GO(7); break;
+    case 8: RP_GO(8); break;
     default: RP_GO(0); break;
   }
 #undef RP_GO

@@ -20,10 +20,10 @@ def main():
     rows = []
     for blk in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
         name = blk.split()[0]
-        m = re.search(r"gemv_repacked_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
+        m = re.search(r"gemv_repacked_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)ELi(n?\d+)ELi(\d+)E", name)
         if not m:
             continue
-        G, T, W, NT, MT, PRO, EPI = map(int, m.groups())
+        G, T, W, NT, MT, PRO, EPI = (int(v.replace("n", "-")) for v in m.groups())
 
         def field(k):
             mm = re.search(k + r": (\d+)", blk)
@@ -33,7 +33,7 @@ def main():
     rows.sort()
     bad = 0
     for r in rows:
-        print("PRO%d EPI%d MT%d W%-2d NT%d G%d T%d  vgpr %3d  scratch %4d  occupancy %d" % r)
+        print("PRO%-2d EPI%d MT%d W%-2d NT%d G%d T%d  vgpr %3d  scratch %4d  occupancy %d" % r)
         bad += r[8] > 0
     print(f"{len(rows)} instantiations, {bad} with scratch")
     return 1 if bad else 0
