@@ -80,12 +80,22 @@ __global__ __launch_bounds__(256) void repack_zs_kernel(const uint32_t* __restri
 // (Pinning a dequantise / MFMA interleave with sched_group_barrier was measured SLOWER, 561 vs 663 TFLOP/s:
 // hipcc's own schedule is kept.)
 
+// MFMA with the accumulator tied in place in the AGPR file.  With the builtin, hipcc picks a different destination
+// than srcC for most of the 128 MFMAs of a K step and repairs that with ~150 v_accvgpr copies per step; the tied
+// "+a" operand leaves it no choice.  (The MFMA results are first read long after the loop; see the s_nop there.)
+__device__ __forceinline__ void mfma_inplace(float4_t& acc, const u32x4_t& a, const u32x4_t& b) {
+  asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
 __device__ __forceinline__ int pf_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }   // [rows][128 halves]
 
 // <WM, WN> waves along M / N; wave tile = (16 MI) x 64 with MI = 8 (4 waves) or 4 (8 waves); workgroup tile BMt x BNt:
 //   <2,2> 256 x 128 (4 waves)   <4,2> 256 x 128 (8 waves, 2 per SIMD)   <1,4> 128 x 256 (4 waves, half the x traffic per CU)
+#ifndef PF_OCC
+#define PF_OCC 1
+#endif
 template <int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void gemm_repacked_tiled_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+__global__ __launch_bounds__(WM * WN * 64, PF_OCC) void gemm_repacked_tiled_kernel(const uint16_t* __restrict__ x, int64_t ldx,
                                                                       const u32x4_t* __restrict__ qw_r, const uint32_t* __restrict__ zs_r,
                                                                       const void* __restrict__ bias, void* __restrict__ y, int M, int K,
                                                                       int N, int g, int NG, int nbx, int nby) {
@@ -112,24 +122,28 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void gemm_repacked_til
     cg[j] = c < NG ? c : NG - 1;                       // clamped: columns >= N are never stored
   }
 
-  u32x4_t a_st[AL];          // next x tile: 256 rows x 16 chunks / threads
   u32x4_t w_cur[4], w_nxt[4];
   uint32_t zs_cur[4], zs_nxt[4];
 
-  auto load_a = [&](int kb) {
+  // the next x tile is staged in two halves (registers -> LDS), each half's loads in flight for half a K step:
+  // 16 staging registers instead of 32 keep the non-accumulator values inside the VGPR file (hipcc otherwise
+  // shuttles accumulators through AGPR copies: 144 v_accvgpr moves per K step)
+  constexpr int AH = AL / 2;
+  u32x4_t a_half[AH];
+  auto load_a = [&](int kb, int half) {
 #pragma unroll
-    for (int i = 0; i < AL; ++i) {
-      const int c = tid + NT_ * i;
+    for (int i = 0; i < AH; ++i) {
+      const int c = tid + NT_ * (half * AH + i);
       const int row = c >> 4, chunk = c & 15;
       const int m = bm + row < M ? bm + row : M - 1;
-      a_st[i] = *(const u32x4_t*)(x + (size_t)m * ldx + kb * 128 + chunk * 8);
+      a_half[i] = *(const u32x4_t*)(x + (size_t)m * ldx + kb * 128 + chunk * 8);
     }
   };
-  auto store_a = [&](int buf) {
+  auto store_a = [&](int buf, int half) {
 #pragma unroll
-    for (int i = 0; i < AL; ++i) {
-      const int c = tid + NT_ * i;
-      *(u32x4_t*)(As + buf * (BMt * 256) + pf_off(c >> 4, c & 15)) = a_st[i];
+    for (int i = 0; i < AH; ++i) {
+      const int c = tid + NT_ * (half * AH + i);
+      *(u32x4_t*)(As + buf * (BMt * 256) + pf_off(c >> 4, c & 15)) = a_half[i];
     }
   };
   auto load_b = [&](u32x4_t (&w)[4], uint32_t (&zs)[4], int kb) {
@@ -147,19 +161,27 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void gemm_repacked_til
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[mi][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
-  load_a(0);
+  load_a(0, 0);
   load_b(w_cur, zs_cur, 0);
-  store_a(0);
+  store_a(0, 0);
+  load_a(0, 1);
+  store_a(0, 1);
   __syncthreads();
 
   const half2_t c960 = {(half_t)960.f, (half_t)960.f};
   for (int kb = 0; kb < KB; ++kb) {
     const int nxt = kb + 1 < KB ? kb + 1 : kb;         // clamped, unconditional prefetch (no branch between load and use)
-    load_a(nxt);
+    load_a(nxt, 0);
     load_b(w_nxt, zs_nxt, nxt);
+    __builtin_amdgcn_sched_barrier(0);                 // or hipcc sinks these loads to the end of the body, right in front of their use
     const unsigned char* Ab = As + (kb & 1) * (BMt * 256);
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
+      if (d == 2) {                                    // first half lands in the other buffer (nobody reads it before the barrier); second half requested
+        store_a((kb + 1) & 1, 0);
+        load_a(nxt, 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       u32x4_t af[MI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) af[mi] = *(const u32x4_t*)(Ab + pf_off(wm * (MI * 16) + mi * 16 + r, d * 4 + q));
@@ -169,15 +191,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void gemm_repacked_til
         const half2_t z1024 = as_h2(pack_hi16(zs_cur[j], zs_cur[j]));
         const u32x4_t frag = rp_dequant(w_cur[j][d], z1024, z1024 - c960, s2);
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-          acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, af[mi]), __builtin_bit_cast(half8_t, frag), acc[mi][j], 0, 0, 0);
+        for (int mi = 0; mi < MI; ++mi) mfma_inplace(acc[mi][j], af[mi], frag);
       }
     }
-    store_a((kb + 1) & 1);                             // the other buffer: nobody reads it until the barrier below
+    store_a((kb + 1) & 1, 1);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { w_cur[j] = w_nxt[j]; zs_cur[j] = zs_nxt[j]; }
     __syncthreads();
   }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results must have left the pipe before the (compiler-scheduled) reads below
 
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -210,7 +232,8 @@ int launch_gemm_repacked_tiled(const GemmArgs& a, const void* packed) {
   const int NG = (a.N + 15) / 16;
   const u32x4_t* qw_r = (const u32x4_t*)packed;
   const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
-  static const int env_shape = getenv("AWQ_PF_SHAPE") ? atoi(getenv("AWQ_PF_SHAPE")) : 14;      // A/B knob: 22, 42, 14
+  static const int env_shape = getenv("AWQ_PF_SHAPE") ? atoi(getenv("AWQ_PF_SHAPE")) : 0;       // A/B knob: 22, 42, 14 = compiler-scheduled tiles
+  if (env_shape == 0) return launch_gemm_repacked_pipelined(a, packed);
   if (env_shape == 22) pf_launch<2, 2>(a, qw_r, zs_r, NG);
   else if (env_shape == 42) pf_launch<4, 2>(a, qw_r, zs_r, NG);
   else pf_launch<1, 4>(a, qw_r, zs_r, NG);
