@@ -58,6 +58,9 @@ __device__ __forceinline__ ZsU zs_unpack(uint32_t zs) {
   return u;
 }
 
+#ifndef PF_ABL
+#define PF_ABL 0            // diagnostic builds only (timing ablations; results are wrong): 1 no dequant stages, 2 no LDS fragment reads in the loop, 4 no x-tile loads / LDS writes, 8 no barrier
+#endif
 constexpr int kPfBM = 128, kPfBN = 256, kPfThreads = 256;
 
 __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(const uint16_t* __restrict__ x, int64_t ldx,
@@ -125,6 +128,7 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
 #pragma unroll
   for (int j = 0; j < 4; ++j) zu[j] = zs_unpack(zs_nxt[j]);
   u32x4_t frag = rp_dequant(w_cur[0][0], zu[0].z1024, zu[0].z64, zu[0].s2);
+  load_a(KB > 1 ? 1 : 0);                              // tile 1 travels while block 0 computes
   __syncthreads();
   u32x4_t af[MI], af_n[MI];
 #pragma unroll
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
     const unsigned char* Ab = As + (kb & 1) * (kPfBM * 256);
     const int nbuf = (kb + 1) & 1;
     const unsigned char* An = As + nbuf * (kPfBM * 256);
-    load_a(nxt);
+    const int nx2 = kb + 2 < KB ? kb + 2 : KB - 1;
     load_b(w_nxt, zs_nxt, nxt);
     __builtin_amdgcn_sched_barrier(0);
 
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
           mfma_tied(acc[mi][j], af[mi], frag);
-          switch (mi) {                                  // (compile-time after unrolling)
+          if constexpr (!(PF_ABL & 1)) switch (mi) {      // (compile-time after unrolling)
             case 0: dq_stage<0>(p, zn.z1024, zn.z64, zn.s2); break;
             case 1: dq_stage<1>(p, zn.z1024, zn.z64, zn.s2); break;
             case 2: dq_stage<2>(p, zn.z1024, zn.z64, zn.s2); break;
@@ -167,18 +171,23 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
             default: break;
           }
           // passengers of the free slots
-          if (d < 3 && j == 1) af_n[mi] = *(const u32x4_t*)(Ab + pfp_off(mi * 16 + r, (d + 1) * 4 + q));   // next k-step's x fragments
-          if (d == 2 && j == 2) store_a1(nbuf, mi);                                     // next x tile -> the other buffer
+          if (!(PF_ABL & 2) && d < 3 && j == 1) af_n[mi] = *(const u32x4_t*)(Ab + pfp_off(mi * 16 + r, (d + 1) * 4 + q));   // next k-step's x fragments
+          if (!(PF_ABL & 4) && d == 2 && j == 2) store_a1(nbuf, mi);                    // next x tile -> the other buffer
+          // ... and the tile after it is requested at once: the 16 workgroups of a row of tiles ask for the same fresh
+          // lines together, so they take about a k-block to arrive (staging cost 29 -> ? us of 190 when given half a block)
+          if (!(PF_ABL & 4) && d == 2 && j == 3 && mi == 0) load_a(nx2);
           if (d == 2 && j == 3 && mi == 7) { pin_here(zs_nxt[0]); zu_nxt[0] = zs_unpack(zs_nxt[0]); }
-          if (d == 3 && j == 0 && mi == 0) __syncthreads();
-          if (d == 3 && j == 1) af_n[mi] = *(const u32x4_t*)(An + pfp_off(mi * 16 + r, q));    // next k-block's first fragments
+          if (!(PF_ABL & 8) && d == 3 && j == 0 && mi == 0) __syncthreads();
+          if (!(PF_ABL & 2) && d == 3 && j == 1) af_n[mi] = *(const u32x4_t*)(An + pfp_off(mi * 16 + r, q));    // next k-block's first fragments
           if (d == 3 && j < 3 && mi == 7) { pin_here(zs_nxt[j + 1]); zu_nxt[j + 1] = zs_unpack(zs_nxt[j + 1]); }
           __builtin_amdgcn_sched_barrier(0);
         }
         frag = p.f;
       }
+      if (!(PF_ABL & 2)) {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) af[mi] = af_n[mi];
+        for (int mi = 0; mi < MI; ++mi) af[mi] = af_n[mi];
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { w_cur[j] = w_nxt[j]; zu[j] = zu_nxt[j]; }
