@@ -93,6 +93,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its wheel bundles its own libamdhip64.so; if this library (linked against the system ROCm's
+    # libamdhip64.so.7) were loaded before it, the process would hold two HIP runtimes and every launch on a torch
+    # stream would fail.  Loaded second, the dependency resolves to the runtime torch already brought in.
+    import torch  # noqa: F401
+
     with _lock:
         if _lib is None:
             if not os.path.exists(LIB_PATH):
