@@ -48,7 +48,7 @@ int launch_gemm_skinny(const GemmArgs& a);
 bool tiled_supported(const GemmArgs& a);
 int launch_gemm_tiled(const GemmArgs& a);
 
-// MFMA-fragment-major re-layout + decode GEMV on it (fp16, K % 128 == 0, g % 128 == 0, M <= 16)
+// MFMA-fragment-major re-layout + the kernels on it (fp16, K % 128 == 0, g % 128 == 0): decode GEMV (M <= 32 per launch)
 size_t repacked_bytes(int64_t K, int64_t N, int64_t g);
 bool repacked_supported(int64_t K, int64_t N, int64_t g, int dtype);
 int launch_repack(const int32_t* qweight, const void* scales, const int32_t* qzeros, void* packed, int64_t K, int64_t N, int64_t g,

@@ -17,8 +17,11 @@
 //                               One wave-wide global_load_dwordx4 = 1 KiB = 128 rows x 16 columns, contiguous.
 //   zs_r[NG][K / g][16]         per (column, quantisation group): low half = scale (fp16 bits), high half =
 //                               fp16(1024 + zero).  Columns >= N are padded with scale 0.
-// A workgroup owns G consecutive column groups (a strip of 16 G columns) for ALL of K; its 8 waves take
+// A workgroup owns G consecutive column groups (a strip of 16 G columns) for ALL of K; its 16 (or 8) waves take
 // consecutive k-block ranges and are summed in fixed order through LDS; y is written directly.
+// Kernels: awq_repacked_gemv.h (decode GEMV template), awq_repacked_fused.hip (its fused variants),
+// awq_repacked_prefill.hip (hand-pipelined prefill GEMM); this file: re-layout, launch heuristics, the
+// compiler-scheduled prefill tiles kept for A/B.
 #include <cstdlib>
 
 #include "awq_repacked_gemv.h"
@@ -70,15 +73,13 @@ __global__ __launch_bounds__(256) void repack_zs_kernel(const uint32_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------ prefill GEMM
-// Large M on the repacked layout.  The B operand never touches LDS: every wave streams the fragment-major
-// dwords of its own 64 columns straight into registers, dequantises each dword into one MFMA B fragment
-// (13 VALU ops, no transposes) and reuses it for 8 row tiles, so per fragment 8 MFMAs (128 cycles of matrix
-// pipe) cover ~60 cycles of VALU issue.  Only x goes through LDS: 256 x 128 halves per K step, double-buffered,
-// 16-byte chunks XOR-swizzled so the 16 rows of a fragment read hit 16 different bank groups; one barrier per
-// K step.  Workgroup = 4 waves (2 x 2), tile 256 x 128, wave tile 128 x 64 = 8 x 4 MFMA 16x16x32 tiles
-// (128 accumulator registers); one workgroup per CU (128 KiB LDS), XCD-aware tile order.
-// (Pinning a dequantise / MFMA interleave with sched_group_barrier was measured SLOWER, 561 vs 663 TFLOP/s:
-// hipcc's own schedule is kept.)
+// Large M on the repacked layout, compiler-scheduled tiles — kept for A/B (AWQ_PF_SHAPE = 14 / 22 / 42); the
+// default is the hand-pipelined form of the <1, 4> decomposition in awq_repacked_prefill.hip.
+// The B operand never touches LDS: every wave streams the fragment-major dwords of its own 64 columns straight
+// into registers, dequantises each dword into one MFMA B fragment (13 VALU ops, no transposes) and reuses it for
+// MI row tiles.  Only x goes through LDS: BMt x 128 halves per K step, double-buffered, 16-byte chunks
+// XOR-swizzled so the 16 rows of a fragment read hit 16 different bank groups; one barrier per K step;
+// XCD-aware tile order.
 
 // MFMA with the accumulator tied in place in the AGPR file.  With the builtin, hipcc picks a different destination
 // than srcC for most of the 128 MFMAs of a K step and repairs that with ~150 v_accvgpr copies per step; the tied

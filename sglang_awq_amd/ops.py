@@ -226,7 +226,8 @@ def awq_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor
 
 def awq_gemm_repacked(input: torch.Tensor, packed: torch.Tensor, K: int, N: int, group_size: int,
                       bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = input @ W (+ bias) from the repacked copy; M <= 16, fp16.  Same numerics as awq_gemm / awq_linear."""
+    """y = input @ W (+ bias) from the repacked copy, any M (GEMV passes of 32 rows up to 160 rows, the MFMA-bound
+    tiled kernel beyond), fp16.  Same numerics as awq_gemm / awq_linear."""
     if input.dim() != 2 or input.shape[1] != K or input.dtype != torch.float16:
         raise RuntimeError(f"awq_gemm_repacked: input must be fp16 [M, {K}], got {input.dtype} {tuple(input.shape)}")
     if input.stride(1) != 1:
