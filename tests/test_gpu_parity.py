@@ -170,6 +170,27 @@ def test_gemm_repacked_vs_oracle(ops, M):
     assert ops.awq_repack(*_dev(*synth.make_awq_weights(256, 64, 128, "bf16", "A", 1))) is None      # bf16: not supported
 
 
+@pytest.mark.parametrize("M", [1, 3, 8])
+def test_gemm_repacked_x_through_lds_vs_oracle(ops, M):
+    """16-wave launches stage x through wave-private LDS (1, 2 or 4 chunks per lane): matrices >= 12 MB packed with
+    2, 4 and 6 k-blocks per wave (the last only fits this way), strips of 1 and 3 column groups, ragged last k-block
+    range (K = 11008: 86 k-blocks over 16 waves), and a batch too large for it (falls back to fragments in registers)."""
+    for (K, N, g) in [(4096, 12288, 128), (8192, 4096, 128), (11008, 4096, 128)]:
+        qw, s, qz = synth.make_awq_weights(K, N, g, "f16", "A", seed=M * 17 + K + N)
+        x = synth.make_activations(M, K, "f16", "A", seed=M + K + 9)
+        b = synth.make_bias(N, "f16", 11)
+        packed = ops.awq_repack(*_dev(qw, s, qz))
+        y = to_np(ops.awq_gemm_repacked(to_torch(x, DEV), packed, K, N, g))
+        _, exact = c_oracle.gemm(x, qw, s, qz, want_exact=True)
+        assert_gemm_close(y, exact, "f16", what=f"repacked (x via LDS) M={M} K={K} N={N}")
+        yb = ops.awq_gemm_repacked(to_torch(x, DEV), packed, K, N, g, to_torch(b, DEV))
+        assert torch.equal(yb, to_torch(y, DEV) + to_torch(b, DEV))
+        # strided x (row stride > K), as a row-parallel slice of a wider activation
+        wide = torch.zeros(M, K + 64, dtype=torch.float16, device=DEV)
+        wide[:, :K] = to_torch(x, DEV)
+        assert torch.equal(ops.awq_gemm_repacked(wide[:, :K], packed, K, N, g), to_torch(y, DEV))
+
+
 def _interleave_np(qw, s, qz):
     """numpy restatement of aux_ops.interleave_gate_up: 16-column groups alternate gate / up."""
     N = s.shape[1]
