@@ -286,7 +286,8 @@ int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
   int G = (NG + 255) / 256;
   bool rounds = false;
   if (G > kRpMaxG) { G = 3; rounds = true; }                       // measured 51 (G = 3) / 53 (2) / 54.5 (4) / 60 (1) us
-  if (two_tiles && G > 4) { G = 4; rounds = true; }                 // 32 rows: reduction scratch 8 x 32 x 64 floats = 64 KiB at most
+  // (32 rows on wide strips: the reduction scratch, 8 waves x 32 x 16 G floats, goes past 64 KiB — that variant runs one
+  // workgroup per CU anyway (190+ registers) and opts in to more of the CU's LDS; narrow rounds would need two resident)
   if (env_g >= 1 && env_g <= kRpMaxG) { G = env_g; rounds = (NG + G - 1) / G > 256; }
   if (G > NG) G = NG;
   const int nwg = (NG + G - 1) / G;
@@ -329,7 +330,7 @@ int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
   const int per_wave = (KB + W - 1) / W;
   size_t lds = (size_t)W * a.M * 16 * G * sizeof(float);
   if (xl) lds += (size_t)W * a.M * (T * 128 + 8) * 2;
-  if (lds > 64 * 1024) return AWQ_ERR_BAD_VARIANT;                      // (M = 32 with 8-group strips: callers fall back to awq_gemm)
+  if (lds > (size_t)(two_tiles ? kRpMaxLds : 64 * 1024)) return AWQ_ERR_BAD_VARIANT;
   if (xl == 1) { rp_launch_g<16, true, 1, -1, 0>(G, a, packed, NG, per_wave, T, nwg, lds); return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH; }
   if (xl == 2) { rp_launch_g<16, true, 1, -2, 0>(G, a, packed, NG, per_wave, T, nwg, lds); return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH; }
   if (xl == 4) { rp_launch_g<16, true, 1, -4, 0>(G, a, packed, NG, per_wave, T, nwg, lds); return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH; }

@@ -9,7 +9,7 @@
 namespace awq {
 
 constexpr int kRpMaxG = 8;
-constexpr int kRpMaxLds = 128 * 1024;      // dynamic LDS the fused variants may ask for (reduction scratch + prologue x)
+constexpr int kRpMaxLds = 144 * 1024;      // dynamic LDS a one-workgroup-per-CU variant may opt in to (of the CU's 160 KiB)
 inline int rp_groups(int64_t N) { return (int)((N + 15) / 16); }
 
 // diagnostic only (tools/kbench rstamps): when set, workgroups write 100 MHz-clock stamps into this device buffer
