@@ -31,7 +31,8 @@ int awq_aux_decode_attention(const void* qkv, const int64_t* pos, const float* c
 /* act[rows, I] = silu(gate_up[:, :I]) * gate_up[:, I:]   (layers/activation.py SiluAndMul) */
 int awq_aux_silu_mul(const void* gate_up, void* act, int64_t rows, int64_t I, void* stream);
 
-/* The repacked decode GEMV (awq_hip.h: awq_gemm_repacked, M <= 16) with its neighbours folded in:
+/* The repacked decode GEMV (awq_hip.h: awq_gemm_repacked; M <= 16, the SiLU-mul epilogue alone up to 32) with its
+ * neighbours folded in:
  *   norm_h != NULL: x is ignored and x = RMSNorm(norm_h + norm_delta) * norm_w is built in the kernel's prologue;
  *                   norm_h_out = norm_h + norm_delta ([M, K], row stride ldx for all three; must not alias norm_h;
  *                   norm_delta must not be NULL — pass zeros).  M * K <= 32768, K <= 8192.

@@ -19,7 +19,20 @@ static void fused_go(int G, const GemmArgs& a, const void* packed, int NG, int p
 int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed) {
   const bool norm = a.norm_h != nullptr;
   if (!norm && !a.silu_mul) return launch_gemv_repacked(a, packed);
-  if (!repacked_supported(a.K, a.N, a.g, a.dtype) || a.M < 1 || a.M > 16 || a.ldx % 8) return AWQ_ERR_BAD_VARIANT;
+  if (!repacked_supported(a.K, a.N, a.g, a.dtype) || a.M < 1 || a.M > 32 || a.ldx % 8) return AWQ_ERR_BAD_VARIANT;
+  if (a.M > 16) {                                                            // two row tiles: SiLU-mul epilogue only, 8 waves
+    if (norm || !a.silu_mul || a.N % 32 || (((uintptr_t)a.x) & 15)) return AWQ_ERR_BAD_VARIANT;
+    const int NG2 = rp_groups(a.N), KB2 = a.K / 128;
+    int G2 = (NG2 + 255) / 256;
+    if (G2 & 1) ++G2;
+    if (G2 > kRpMaxG || G2 > NG2) return AWQ_ERR_BAD_VARIANT;
+    const int pw = (KB2 + 7) / 8;
+    const int T2 = (pw == 4 && rp_fits(8, 2, G2, 4)) ? 4 : 0;
+    const size_t lds2 = (size_t)8 * a.M * 16 * G2 * sizeof(float);
+    if (lds2 > (size_t)kRpMaxLds) return AWQ_ERR_BAD_VARIANT;
+    rp_launch_g<8, true, 2, 0, 1>(G2, a, packed, NG2, pw, T2, (NG2 + G2 - 1) / G2, lds2);
+    return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+  }
   if (!norm && (((uintptr_t)a.x) & 15)) return AWQ_ERR_BAD_VARIANT;
   if (a.silu_mul && a.N % 32) return AWQ_ERR_BAD_VARIANT;                  // whole (gate, up) pairs of 16-column groups
   constexpr int W = 16;

@@ -350,6 +350,7 @@ static void rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wav
 #define RP_GO(TT)                                                                                                                     \
   if constexpr ((PRO == 0 && EPI == 0) ? (TT <= 6 && rp_fits(W, MT, G, TT) && (MT == 1 || TT == 0 || TT == 4))                           \
                 : (PRO < 0)            ? (W == 16 && NT && MT == 1 && !(EPI && (G & 1)) && rp_fits_xl(G, TT))                            \
+                : (MT == 2)            ? (PRO == 0 && W == 8 && NT && !(G & 1) && rp_fits(8, 2, G, TT))   /* SiLU-mul epilogue, 17..32 rows */ \
                                        : (TT <= 6 && W == 16 && NT && MT == 1 && rp_fits_fused(G, TT, PRO, EPI))) {                      \
     auto kern = gemv_repacked_kernel<G, TT, W, NT, MT, PRO, EPI>;                                                                       \
     if (lds > 64 * 1024) {                       /* one workgroup per CU: opt in to more of its 160 KiB of LDS, once */                  \

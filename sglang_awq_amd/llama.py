@@ -133,7 +133,7 @@ class LlamaDecoderLayer(torch.nn.Module):
                                         self.head_dim)
         o, _ = self.o_proj(attn.reshape(B, self.q_size))
         act = None
-        gu_il = self._gate_up_interleaved() if B <= 16 else None
+        gu_il = self._gate_up_interleaved() if B <= 32 else None
         if gu_il is not None:
             dims = self._awq_dims(self.gate_up_proj)
             r = None

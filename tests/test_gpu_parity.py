@@ -490,3 +490,25 @@ def test_gemv_repacked_fused_refuses_what_it_cannot_run(ops):
         h = torch.zeros(M, K, dtype=torch.float16, device=DEV)
         w = torch.ones(K, dtype=torch.float16, device=DEV)
         assert aux_ops.gemv_repacked_fused(packed, K, N, 128, norm=(h, h.clone(), w, 1e-5)) is None
+
+
+@pytest.mark.parametrize("M", [17, 32])
+def test_gemv_repacked_silu_epilogue_two_row_tiles(ops, M):
+    """SiLU-mul epilogue on the two-row-tile variant (17..32 rows): straight-line (4 k-blocks per wave) and loop depth,
+    strips of 2 and 6 groups (the latter with more than 64 KiB of reduction scratch)."""
+    from sglang_awq_amd import aux_ops
+
+    for (K, N, g) in [(4096, 2112, 128), (1024, 22016, 128), (4096, 22016, 128)]:
+        qw, s, qz = synth.make_awq_weights(K, N, g, "f16", "A", seed=M * 5 + K + N)
+        x = synth.make_activations(M, K, "f16", "A", seed=M + K + 2)
+        packed_il = ops.awq_repack(*aux_ops.interleave_gate_up(*_dev(qw, s, qz)))
+        r = aux_ops.gemv_repacked_fused(packed_il, K, N, g, x=to_torch(x, DEV), silu_mul=True)
+        assert r is not None, f"M={M} K={K} N={N}"
+        _, exact = c_oracle.gemm(x, qw, s, qz, want_exact=True)
+        gu = exact.astype(np.float16)
+        gate, up = gu[:, :N // 2].astype(np.float32), gu[:, N // 2:]
+        want = ((gate / (1.0 + np.exp(-gate))).astype(np.float16) * up).astype(np.float64)
+        got = to_np(r[0]).astype(np.float64)
+        tol = 2.0 * ulp(want, "f16") + 2e-3 * (1.0 + np.abs(exact[:, N // 2:]))
+        assert got.shape == (M, N // 2) and np.all(np.abs(got - want) <= tol), f"M={M} K={K} N={N}: worst {np.abs(got - want).max():.3e}"
+        assert float((got != want).mean()) < 0.05
