@@ -54,10 +54,15 @@ int awq_dequantize(const int32_t* qweight, const void* scales, const int32_t* qz
   return launch_dequantize(qweight, scales, qzeros, out, K, N, group_size, dtype, (hipStream_t)stream);
 }
 
+// Prefill-sized calls of the op re-lay the weight out on the fly: one pass over the packed weight into the workspace
+// (awq_repack, ~40 us at 4096 x 11008) buys the hand-pipelined kernel of the fragment-major layout (191 us at
+// M = 2048) instead of the checkpoint-layout tiles (311 us); below ~800 rows the pass costs more than it saves.
+constexpr int64_t kRepackOnTheFlyMinM = 1024;
+constexpr size_t kWorkspaceHead = 4096;        // arrival counters of the split-K kernel live here
+
 size_t awq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t group_size, int dtype) {
-  (void)group_size;
-  (void)dtype;
-  if (M <= 0 || K <= 0 || N <= 0) return 4096;
+  if (M <= 0 || K <= 0 || N <= 0) return kWorkspaceHead;
+  if (M >= kRepackOnTheFlyMinM && repacked_supported(K, N, group_size, dtype)) return kWorkspaceHead + repacked_bytes(K, N, group_size);
   return skinny_workspace_bytes(M, K, N);
 }
 
@@ -107,6 +112,13 @@ int awq_gemm_ex(const void* x, int64_t ldx, const int32_t* qweight, const void* 
       }
       return AWQ_OK;
     }
+  }
+  if (M >= kRepackOnTheFlyMinM && repacked_supported(K, N, group_size, dtype) && workspace && (((uintptr_t)workspace) & 15) == 0 &&
+      workspace_bytes >= kWorkspaceHead + repacked_bytes(K, N, group_size) && a.ldx % 8 == 0 && (((uintptr_t)x) & 15) == 0) {
+    void* packed = (char*)workspace + kWorkspaceHead;
+    rc = launch_repack(qweight, scales, qzeros, packed, K, N, group_size, dtype, a.stream);
+    if (rc) return rc;
+    return launch_gemm_repacked_tiled(a, packed);
   }
   if (tiled_supported(a)) return launch_gemm_tiled(a);
   return launch_gemm_generic(a);

@@ -132,6 +132,11 @@ def _gemm_impl(input, qweight, scales, qzeros, bias, split_k_iters, variant=_lib
             return y
         stream = torch.cuda.current_stream(dev).cuda_stream
         ws = _workspace(dev)
+        need = lib.awq_gemm_workspace_bytes(M, K, N, g, _DTYPE_CODE[scales.dtype])
+        if need > ws.numel():
+            # prefill-sized call on a large matrix: room for the on-the-fly re-layout; a per-call buffer from the caching
+            # allocator (nothing in it needs to start at zero — the arrival counters are not used on that path)
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
         rc = lib.awq_gemm_ex(_vp(input), ldx, _vp(qweight), _vp(scales), _vp(qzeros), _vp(bias), _vp(y), _vp(ws),
                              ws.numel(), M, K, N, g, _DTYPE_CODE[scales.dtype], split_k_iters, variant, tune,
                              ctypes.c_void_p(stream))

@@ -512,3 +512,21 @@ def test_gemv_repacked_silu_epilogue_two_row_tiles(ops, M):
         tol = 2.0 * ulp(want, "f16") + 2e-3 * (1.0 + np.abs(exact[:, N // 2:]))
         assert got.shape == (M, N // 2) and np.all(np.abs(got - want) <= tol), f"M={M} K={K} N={N}: worst {np.abs(got - want).max():.3e}"
         assert float((got != want).mean()) < 0.05
+
+
+def test_awq_gemm_op_prefill_repacks_on_the_fly(ops):
+    """The drop-in op at prefill-sized M (>= 1024) re-lays the weight out into workspace and runs the kernel of the
+    repacked path: bit-identical to awq_gemm_repacked on a persistent copy, within the GEMM bound of the oracle (first
+    rows), also on a matrix whose repacked copy exceeds the shim's persistent 32 MiB scratch and with a bias."""
+    for (M, K, N) in [(1024, 512, 1056), (1100, 4096, 22016)]:
+        qw, s, qz = synth.make_awq_weights(K, N, 128, "f16", "A", seed=M + N)
+        x = synth.make_activations(M, K, "f16", "A", seed=M + 1)
+        b = synth.make_bias(N, "f16", 3)
+        dq, ds, dz = _dev(qw, s, qz)
+        y = torch.ops.sgl_kernel.awq_gemm(to_torch(x, DEV), dq, ds, dz, 8)
+        packed = ops.awq_repack(dq, ds, dz)
+        assert torch.equal(y, ops.awq_gemm_repacked(to_torch(x, DEV), packed, K, N, 128))
+        _, exact = c_oracle.gemm(x[:4], qw, s, qz, want_exact=True)
+        assert_gemm_close(to_np(y[:4]), exact, "f16", what=f"awq_gemm op, prefill M={M} K={K} N={N}")
+        yb = ops.awq_linear(to_torch(x, DEV), dq, ds, dz, to_torch(b, DEV))
+        assert torch.equal(yb, y + to_torch(b, DEV))
