@@ -92,14 +92,17 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
   uint32_t zs_nxt[4];
   ZsU zu[4], zu_nxt[4];
 
+  const uint16_t* xrow[AL];                            // this thread's AL rows / chunks of the x tile, k-block 0
+#pragma unroll
+  for (int i = 0; i < AL; ++i) {
+    const int c = tid + kPfThreads * i;
+    const int row = c >> 4, chunk = c & 15;
+    const int m = bm + row < M ? bm + row : M - 1;
+    xrow[i] = x + (size_t)m * ldx + chunk * 8;
+  }
   auto load_a = [&](int kb) {
 #pragma unroll
-    for (int i = 0; i < AL; ++i) {
-      const int c = tid + kPfThreads * i;
-      const int row = c >> 4, chunk = c & 15;
-      const int m = bm + row < M ? bm + row : M - 1;
-      a_st[i] = *(const u32x4_t*)(x + (size_t)m * ldx + kb * 128 + chunk * 8);
-    }
+    for (int i = 0; i < AL; ++i) a_st[i] = *(const u32x4_t*)(xrow[i] + kb * 128);
   };
   auto store_a1 = [&](int buf, int i) {
     const int c = tid + kPfThreads * i;
@@ -172,10 +175,12 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
           }
           // passengers of the free slots
           if (!(PF_ABL & 2) && d < 3 && j == 1) af_n[mi] = *(const u32x4_t*)(Ab + pfp_off(mi * 16 + r, (d + 1) * 4 + q));   // next k-step's x fragments
-          if (!(PF_ABL & 4) && d == 2 && j == 2) store_a1(nbuf, mi);                    // next x tile -> the other buffer
-          // ... and the tile after it is requested at once: the 16 workgroups of a row of tiles ask for the same fresh
-          // lines together, so they take about a k-block to arrive (staging cost 29 -> ? us of 190 when given half a block)
-          if (!(PF_ABL & 4) && d == 2 && j == 3 && mi == 0) load_a(nx2);
+          // next x tile -> the other buffer, one 1 KiB write every fourth MFMA (eight in a row from all four waves
+          // collide with the fragment reads), then the tile after it is requested at once: the 16 workgroups of a
+          // row of tiles ask for the same fresh lines together, so they take about a k-block to arrive
+          if (!(PF_ABL & 4) && ((d == 1 && j >= 2) || (d == 2 && j <= 1)) && (mi & 3) == 0)
+            store_a1(nbuf, ((d - 1) * 4 + j - 2) * 2 + (mi >> 2));
+          if (!(PF_ABL & 4) && d == 2 && j == 2 && mi == 0) load_a(nx2);
           if (d == 2 && j == 3 && mi == 7) { pin_here(zs_nxt[0]); zu_nxt[0] = zs_unpack(zs_nxt[0]); }
           if (!(PF_ABL & 8) && d == 3 && j == 0 && mi == 0) __syncthreads();
           if (!(PF_ABL & 2) && d == 3 && j == 1) af_n[mi] = *(const u32x4_t*)(An + pfp_off(mi * 16 + r, q));    // next k-block's first fragments

@@ -72,6 +72,33 @@ def test_argument_validation_without_gpu(lib):
     assert lib.awq_gemm_ex(vp(p), 128, vp(p), vp(p), vp(p), None, vp(p), vp(p), 4096, 1, 128, 64, 128, 0, 1, 99, 0, None) == -7
 
 
+def test_aux_argument_validation_without_gpu(lib):
+    """include/awq_aux.h entry points: rejections that return before any HIP call, and shapes the fused GEMV has no
+    instantiation for (AWQ_ERR_BAD_VARIANT = -7: the caller runs the separate ops)."""
+    buf = (ctypes.c_char * 4096)()
+    p = (ctypes.cast(buf, ctypes.c_void_p).value + 15) & ~15
+    vp = ctypes.c_void_p
+    f = lambda **kw: lib.awq_aux_gemv_repacked_fused(kw.get("x", vp(p)), kw.get("ldx", 4096), kw.get("packed", vp(p)), kw.get("y", vp(p)),
+                                                     kw.get("M", 1), kw.get("K", 4096), kw.get("N", 4096), kw.get("g", 128), 0,
+                                                     kw.get("h", None), kw.get("delta", None), kw.get("w", None), kw.get("h_out", None),
+                                                     1e-5, kw.get("silu", 1), None)
+    assert f(packed=None) == -1 and f(y=None) == -1 and f(x=None) == -1
+    assert f(N=4092) == -2 and f(K=4100) == -2 and f(M=0) == -2 and f(ldx=128) == -2
+    assert f(packed=vp(p + 4)) == -6
+    assert f(M=33) == -7                                              # more than two row tiles
+    assert f(g=64) == -7                                              # no repacked form for g = 64
+    assert f(N=4104) == -7                                            # SiLU-mul needs whole (gate, up) pairs of 16-column groups
+    assert f(h=vp(p), delta=None, w=vp(p), h_out=vp(p + 64), silu=0) == -7        # norm prologue without delta
+    assert f(h=vp(p), delta=vp(p), w=vp(p), h_out=vp(p), silu=0) == -7             # h_out aliases h
+    assert f(M=16, h=vp(p), delta=vp(p), w=vp(p), h_out=vp(p + 64), silu=0) == -7  # too many rows for the prologue
+    assert f(K=16384, ldx=16384, h=vp(p), delta=vp(p), w=vp(p), h_out=vp(p + 64), silu=0) == -7   # > 4 k-blocks per wave
+    assert lib.awq_aux_decode_attention(None, vp(p), vp(p), vp(p), vp(p), vp(p), vp(p), 1, 8, 8, 128, 64, 1.0, None) == -1
+    assert lib.awq_aux_decode_attention(vp(p), vp(p), vp(p), vp(p), vp(p), vp(p), vp(p), 1, 8, 3, 128, 64, 1.0, None) == -2    # Hq % Hkv
+    assert lib.awq_aux_decode_attention(vp(p), vp(p), vp(p), vp(p), vp(p), vp(p), vp(p), 1, 8, 8, 96, 64, 1.0, None) == -2     # head dim
+    assert lib.awq_aux_add_rmsnorm(vp(p), None, vp(p), vp(p), 1, 100, 1e-5, None) == -2      # H % 8
+    assert lib.awq_aux_silu_mul(vp(p), None, 1, 64, None) == -1
+
+
 def test_workspace_query(lib):
     small = lib.awq_gemm_workspace_bytes(1, 4096, 11008, 128, 0)
     assert 4096 <= small <= 4096 + (32 << 20)
