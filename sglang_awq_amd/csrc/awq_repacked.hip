@@ -317,7 +317,7 @@ int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
     const int pw = (KB + 15) / 16;
     const int per_lane = (a.M * pw * 16 + 63) / 64;
     const size_t need = (size_t)16 * a.M * 16 * G * sizeof(float) + (size_t)16 * a.M * (pw * 128 + 8) * 2;
-    if (rp_fits_xl(G, pw) && per_lane <= 4 && need <= 64 * 1024) {
+    if (rp_fits_xl(G, pw) && per_lane <= 4 && need <= (size_t)kRpMaxLds) {
       xl = per_lane <= 1 ? 1 : per_lane <= 2 ? 2 : 4;
       T = pw;
     }
@@ -330,7 +330,7 @@ int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
   const int per_wave = (KB + W - 1) / W;
   size_t lds = (size_t)W * a.M * 16 * G * sizeof(float);
   if (xl) lds += (size_t)W * a.M * (T * 128 + 8) * 2;
-  if (lds > (size_t)(two_tiles ? kRpMaxLds : 64 * 1024)) return AWQ_ERR_BAD_VARIANT;
+  if (lds > (size_t)(two_tiles || xl ? kRpMaxLds : 64 * 1024)) return AWQ_ERR_BAD_VARIANT;
   if (xl == 1) { rp_launch_g<16, true, 1, -1, 0>(G, a, packed, NG, per_wave, T, nwg, lds); return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH; }
   if (xl == 2) { rp_launch_g<16, true, 1, -2, 0>(G, a, packed, NG, per_wave, T, nwg, lds); return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH; }
   if (xl == 4) { rp_launch_g<16, true, 1, -4, 0>(G, a, packed, NG, per_wave, T, nwg, lds); return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH; }

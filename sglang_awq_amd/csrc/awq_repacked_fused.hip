@@ -54,7 +54,7 @@ int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed) {
   if (!norm) {                                                               // SiLU-mul epilogue only: x through wave-private LDS when it fits
     const int per_lane = (a.M * T * 16 + 63) / 64;
     const size_t xl_lds = lds + (size_t)W * a.M * (T * 128 + 8) * 2;
-    if (rp_fits_xl(G, T) && per_lane <= 4 && xl_lds <= 64 * 1024) {
+    if (rp_fits_xl(G, T) && per_lane <= 4 && xl_lds <= (size_t)kRpMaxLds) {
       if (per_lane <= 1) fused_go<-1, 1>(G, a, packed, NG, T, T, nwg, xl_lds);
       else if (per_lane <= 2) fused_go<-2, 1>(G, a, packed, NG, T, T, nwg, xl_lds);
       else fused_go<-4, 1>(G, a, packed, NG, T, T, nwg, xl_lds);
