@@ -1,6 +1,8 @@
 // extern "C" entry points declared in include/awq_hip.h: argument validation, variant choice,
 // launch.  No allocation, no synchronisation, no global mutable state beyond a once-only kernel
 // attribute in the skinny launcher.
+#include <cstdlib>
+
 #include "awq_kernels.h"
 
 namespace {
@@ -21,6 +23,34 @@ int check_common(const void* qweight, const void* scales, const void* qzeros, in
 bool pow2_le32(int v) { return v >= 1 && v <= 32 && (v & (v - 1)) == 0; }
 
 }  // namespace
+
+// Kernel choice on the fragment-major layout, shared by awq_gemm_repacked and the op's on-the-fly re-layout (so the two
+// routes give bit-identical results).
+static int repacked_dispatch(const GemmArgs& a, const void* packed) {
+  const int64_t M = a.M;
+  // <= 32 rows: the streaming GEMV.  Up to 160 rows, passes of it (32 rows each) beat the 128 x 256 MFMA tiles, which
+  // would leave most CUs idle (4096 x 11008: 13.6 us per pass vs ~62 us for one round of under-filled tiles).  Where the
+  // wide tiles are few (narrow matrices, up to 512 rows) 128 x 64 tiles with the K split inside the workgroup fill the
+  // chip better (11008 x 4096 at M = 256: 142 -> 100 us); beyond that the hand-pipelined wide tiles.
+  static const int env_mid = getenv("AWQ_MID") ? atoi(getenv("AWQ_MID")) : 1;      // A/B knob: 0 = never the 128 x 64 tiles
+  if (M <= 32) return launch_gemv_repacked(a, packed);
+  const bool aligned = a.ldx % 8 == 0 && (((uintptr_t)a.x) & 15) == 0;
+  const int64_t wide_tiles = ((M + 127) / 128) * ((a.N + 255) / 256);
+  if (env_mid != 0 && aligned && M > 96 && wide_tiles <= 64) return launch_gemm_repacked_ksplit(a, packed);
+  if (M <= 160) {
+    const size_t eb2 = 2;
+    for (int64_t m0 = 0; m0 < M; m0 += 32) {
+      GemmArgs c = a;
+      c.M = (int)(M - m0 < 32 ? M - m0 : 32);
+      c.x = (const char*)a.x + (size_t)m0 * a.ldx * eb2;
+      c.y = (char*)a.y + (size_t)m0 * a.N * eb2;
+      const int rc = launch_gemv_repacked(c, packed);
+      if (rc) return rc;
+    }
+    return AWQ_OK;
+  }
+  return launch_gemm_repacked_tiled(a, packed);
+}
 
 extern "C" {
 
@@ -118,7 +148,7 @@ int awq_gemm_ex(const void* x, int64_t ldx, const int32_t* qweight, const void* 
     void* packed = (char*)workspace + kWorkspaceHead;
     rc = launch_repack(qweight, scales, qzeros, packed, K, N, group_size, dtype, a.stream);
     if (rc) return rc;
-    return launch_gemm_repacked_tiled(a, packed);
+    return repacked_dispatch(a, packed);
   }
   if (tiled_supported(a)) return launch_gemm_tiled(a);
   return launch_gemm_generic(a);
@@ -156,23 +186,7 @@ int awq_gemm_repacked(const void* x, int64_t ldx, const void* packed, const void
   a.workspace = nullptr; a.workspace_bytes = 0;
   a.M = (int)M; a.K = (int)K; a.N = (int)N; a.g = (int)group_size; a.dtype = dtype; a.tune = 0;
   a.stream = (hipStream_t)stream;
-  // decode batches: the streaming GEMV (32 rows per pass).  Up to 160 rows, passes of it beat the 256-row tiles of
-  // the MFMA-bound kernel, which would leave 2/3 of the CUs idle (measured at 4096 x 11008: 13.6 us per 32-row pass
-  // vs ~80 us for one wave of 256-row tiles); beyond that the tiled kernel.
-  if (M <= 160) {
-    const size_t eb2 = 2;
-    for (int64_t m0 = 0; m0 < M; m0 += 32) {
-      GemmArgs c = a;
-      c.M = (int)(M - m0 < 32 ? M - m0 : 32);
-      c.x = (const char*)x + (size_t)m0 * ldx * eb2;
-      c.y = (char*)y + (size_t)m0 * N * eb2;
-      const int rc = launch_gemv_repacked(c, packed);
-      if (rc == AWQ_ERR_BAD_VARIANT && M > 32) break;          // strip too wide for the 32-row scratch: tiled kernel instead
-      if (rc) return rc;
-      if (m0 + 32 >= M) return AWQ_OK;
-    }
-  }
-  return launch_gemm_repacked_tiled(a, packed);
+  return repacked_dispatch(a, packed);
 }
 
 }  // extern "C"

@@ -56,6 +56,7 @@ int launch_repack(const int32_t* qweight, const void* scales, const int32_t* qze
 int launch_gemv_repacked(const GemmArgs& a, const void* packed);
 int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed);   // norm prologue and / or SiLU-mul epilogue (awq_repacked_fused.hip)
 int launch_gemm_repacked_tiled(const GemmArgs& a, const void* packed);   // any M, MFMA-bound prefill shapes
+int launch_gemm_repacked_ksplit(const GemmArgs& a, const void* packed);      // 128 x 64 tiles, K split inside the workgroup (middle M)
 int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed);   // its hand-pipelined 128 x 256 form (awq_repacked_prefill.hip)
 
 }  // namespace awq

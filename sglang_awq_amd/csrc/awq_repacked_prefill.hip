@@ -14,6 +14,8 @@
 //     k-block's scales / zeros ride in the same slots; the one barrier per k-block sits inside its last k-step so the
 //     next block's first fragments are fetched behind it in the MFMA shadow.
 // Numerics are those of rp_dequant (same operations in the same order per element).
+#include <type_traits>
+
 #include "awq_repacked_gemv.h"
 
 namespace awq {
@@ -223,6 +225,161 @@ int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed) {
   static const hipError_t once = hipFuncSetAttribute((const void*)gemm_repacked_pipelined_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)once;
   hipLaunchKernelGGL(gemm_repacked_pipelined_kernel, dim3(nbx * nby), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r,
+                     a.bias, a.y, a.M, a.K, a.N, a.g, NG, nbx, nby);
+  return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
+
+
+// ------------------------------------------------------------------------------------------ middle M, few wide tiles
+// 128 x 64 tiles, K split inside the workgroup.  The 128 x 256 tiles above give only N / 256 x M / 128 workgroups
+// (16 per 128 rows for N = 4096), and 32-row GEMV passes re-stream the weight per pass.  Here a workgroup owns
+// 128 rows x 64 columns and its four waves split every 128-deep K block by k-step (wave w takes rows
+// k = 32 w .. 32 w + 31 of each block: dword w of the fragment-major dwordx4), so a wave still reuses each dequantised
+// fragment for 8 row tiles; the four partial tiles are summed in fixed order through LDS at the end (no workspace,
+// deterministic).  Four times the workgroups of the wide tile, the weight streamed once.
+// Compiler-scheduled (accumulators tied in AGPRs); a K block is ~1 us here against ~0.35 us of MFMA work (removing
+// the x loads, the LDS staging and the barrier together only brings 48 us down to 33 at M = 128, 4096 x 11008: the
+// dequantise -> MFMA chain of one wave per SIMD is the cost), so it is dispatched only where it measured faster than
+// the alternatives: 11008 x 4096 at M = 256 / 512: 142 -> 100 / 108 us; 4096 x 11008 at M = 128: 54 -> 41 us.
+__global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_ksplit_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+                                                                             const uint32_t* __restrict__ qw_r,
+                                                                             const uint32_t* __restrict__ zs_r,
+                                                                             const void* __restrict__ bias, void* __restrict__ y, int M,
+                                                                             int K, int N, int g, int NG, int nbx, int nby) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char As[];      // 2 x 32 KiB of x, later 4 x 32 KiB of partial tiles
+  constexpr int MI = 8, AL = 8, BN = 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, r = lane & 15;
+  const int KB = K / 128, groups = K / g;
+
+  const int nwg = nbx * nby, bid = blockIdx.x;
+  const int xcd = bid & 7, qd = nwg >> 3, rem = nwg & 7;
+  const int logical = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (bid >> 3);
+  const int bm = (logical / nbx) * kPfBM;
+  const int bn = (logical % nbx) * BN;
+
+  size_t woff[4], zoff[4];                              // dword offsets of this lane's weight dword / scale word, k-block 0
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int c = bn / 16 + j;
+    if (c >= NG) c = NG - 1;                             // clamped: columns >= N are never stored
+    woff[j] = ((size_t)c * KB * 64 + lane) * 4 + wave;
+    zoff[j] = (size_t)c * groups * 16 + r;
+  }
+  const uint16_t* xrow[AL];
+#pragma unroll
+  for (int i = 0; i < AL; ++i) {
+    const int c = tid + kPfThreads * i;
+    const int row = c >> 4, chunk = c & 15;
+    const int m = bm + row < M ? bm + row : M - 1;
+    xrow[i] = x + (size_t)m * ldx + chunk * 8;
+  }
+  // Two x tiles and two sets of weight dwords in flight (the loop is unrolled by two so their registers alternate): a
+  // K block is only ~0.35 us of MFMA work here, a load takes ~1 us — with one tile in flight the kernel ran at the
+  // latency-bound 32 KB per us per CU (1.25 us per K block).
+  u32x4_t a_st[2][AL];
+  uint32_t w_buf[2][4], zs_buf[2][4];
+  auto load_a = [&](u32x4_t (&dst)[AL], int kb) {
+#pragma unroll
+    for (int i = 0; i < AL; ++i) dst[i] = *(const u32x4_t*)(xrow[i] + kb * 128);
+  };
+  auto store_a = [&](const u32x4_t (&src)[AL], int buf) {
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      const int c = tid + kPfThreads * i;
+      *(u32x4_t*)(As + buf * (kPfBM * 256) + pfp_off(c >> 4, c & 15)) = src[i];
+    }
+  };
+  auto load_b = [&](uint32_t (&w)[4], uint32_t (&zs)[4], int kb) {
+    const int grp = (kb * 128) / g;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w[j] = qw_r[woff[j] + (size_t)kb * 256];
+      zs[j] = zs_r[zoff[j] + (size_t)grp * 16];
+    }
+  };
+
+  float4_t acc[MI][4];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[mi][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+  // tile t travels in a_st[t & 1], is written to LDS buffer t & 1 at the end of step t - 1 and consumed in step t
+  load_a(a_st[0], 0);
+  load_b(w_buf[0], zs_buf[0], 0);
+  load_b(w_buf[1], zs_buf[1], KB > 1 ? 1 : 0);
+  store_a(a_st[0], 0);
+  load_a(a_st[1], KB > 1 ? 1 : 0);
+  __syncthreads();
+
+  auto step = [&](auto P_, int kb) {
+    constexpr int P = decltype(P_)::value;
+    const int k2 = kb + 2 < KB ? kb + 2 : KB - 1;       // clamped, unconditional prefetch
+    uint32_t wv[4], zv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wv[j] = w_buf[P][j]; zv[j] = zs_buf[P][j]; }
+    load_a(a_st[P], k2);                                 // (tile kb already sits in LDS buffer P)
+    load_b(w_buf[P], zs_buf[P], k2);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* Ab = As + P * (kPfBM * 256);
+    u32x4_t af[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) af[mi] = *(const u32x4_t*)(Ab + pfp_off(mi * 16 + r, wave * 4 + q));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const ZsU u = zs_unpack(zv[j]);
+      const u32x4_t frag = rp_dequant(wv[j], u.z1024, u.z64, u.s2);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) mfma_tied(acc[mi][j], af[mi], frag);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    store_a(a_st[P ^ 1], P ^ 1);                         // tile kb + 1, requested a full step ago; nobody reads that buffer until the barrier
+    __syncthreads();
+  };
+  for (int kb = 0; kb < KB; kb += 2) {
+    step(std::integral_constant<int, 0>{}, kb);
+    if (kb + 1 < KB) step(std::integral_constant<int, 1>{}, kb + 1);
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the last MFMAs' results must have left the pipe before the reads below
+
+  // partial tiles -> LDS [wave][mi][j][i][lane] (conflict-free: consecutive lanes, consecutive floats), summed in wave order
+  float* red = (float*)As;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[(((wave * MI + mi) * 4 + j) * 4 + i) * 64 + lane] = acc[mi][j][i];
+  __syncthreads();
+  // thread t finishes (mi = 2 * wave + {0, 1}, all j, i) for its lane: 32 outputs
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int mi = wave * 2 + h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = bm + mi * 16 + 4 * q + i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = bn + j * 16 + r;
+        float v = red[(((0 * MI + mi) * 4 + j) * 4 + i) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += red[(((w * MI + mi) * 4 + j) * 4 + i) * 64 + lane];
+        if (m < M && n < N) store_output<AWQ_DTYPE_F16>(y, (size_t)m * N + n, v, bias, n);
+      }
+    }
+  }
+}
+
+int launch_gemm_repacked_ksplit(const GemmArgs& a, const void* packed) {
+  const int NG = rp_groups(a.N);
+  const uint32_t* qw_r = (const uint32_t*)packed;
+  const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
+  const int nbx = (a.N + 63) / 64, nby = (a.M + kPfBM - 1) / kPfBM;
+  const size_t lds = 4 * 8 * 4 * 4 * 64 * sizeof(float);                  // 128 KiB: four partial tiles (covers the 64 KiB of x buffers)
+  static const hipError_t once = hipFuncSetAttribute((const void*)gemm_repacked_ksplit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)once;
+  hipLaunchKernelGGL(gemm_repacked_ksplit_kernel, dim3(nbx * nby), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r,
                      a.bias, a.y, a.M, a.K, a.N, a.g, NG, nbx, nby);
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }

@@ -266,9 +266,13 @@ def test_gemv_repacked_fused_vs_oracle(ops, M):
 
 
 def test_gemm_repacked_tiled_vs_oracle(ops):
-    """M > 32 on the repacked copy: the register-direct-B tiled kernel; ragged M / N against its 256 x 128 tile."""
-    for (M, K, N, g) in [(33, 128, 128, 128), (64, 256, 136, 128), (100, 512, 1056, 128), (256, 1024, 256, 1024),
-                         (257, 384, 264, 128), (300, 256, 2304, 128), (1024, 128, 64, 128)]:
+    """M > 32 on the repacked copy.  Three routes (awq_capi.hip repacked_dispatch): 32-row GEMV passes (<= 96 rows, or
+    <= 160 with many column tiles), 128 x 64 tiles with the K split inside the workgroup (> 96 rows, <= 64 wide tiles),
+    hand-pipelined 128 x 256 tiles (the rest); ragged M / N against each tile, odd and even K-block counts."""
+    for (M, K, N, g) in [(33, 128, 128, 128), (64, 256, 136, 128), (150, 128, 16648, 128),            # GEMV passes
+                         (100, 512, 1056, 128), (256, 1024, 256, 1024), (257, 384, 264, 128), (300, 256, 2304, 128),
+                         (1024, 128, 64, 128), (97, 640, 72, 128),                                      # K-split tiles
+                         (600, 256, 4360, 128), (161, 384, 16640, 128), (520, 128, 3336, 128)]:         # pipelined tiles
         qw, s, qz = synth.make_awq_weights(K, N, g, "f16", "A", seed=M * 3 + K + N)
         x = synth.make_activations(M, K, "f16", "A", seed=M + K + 1)
         packed = ops.awq_repack(*_dev(qw, s, qz))
