@@ -257,6 +257,44 @@ def main():
         torch.cuda.synchronize()
         op_us = e0.elapsed_time(e1) * 1e3 / (reps * sets)
 
+    # context only (not the metric): the same decode kernel on a 70B-class matrix, where the fixed per-launch costs
+    # (kernel boundary, time to first load, reduction) amortise — what fraction of peak the kernel itself reaches
+    big = None
+    if rank == 0 and world == 1 and M == 1:
+        BK, BN, nb = 8192, 28672, 5                      # 5 x 122 MB of packed weight: more than 2 x the Infinity Cache
+        gen = torch.Generator(device=dev); gen.manual_seed(99)
+        packs = []
+        for _ in range(nb):
+            bqw = torch.randint(-2 ** 31, 2 ** 31 - 1, (BK, BN // 8), dtype=torch.int64, device=dev, generator=gen).to(torch.int32)
+            bqz = torch.randint(-2 ** 31, 2 ** 31 - 1, (BK // GROUP, BN // 8), dtype=torch.int64, device=dev, generator=gen).to(torch.int32)
+            bsc = (0.005 + 0.015 * torch.rand((BK // GROUP, BN), device=dev, generator=gen)).half()
+            packs.append(ops.awq_repack(bqw, bsc, bqz))
+            del bqw, bqz, bsc
+        xb = torch.randn(1, BK, device=dev, generator=gen).half()
+
+        def big_pass():
+            for pk in packs:
+                ops.awq_gemm_repacked(xb, pk, BK, BN, GROUP)
+        big_pass()
+        torch.cuda.synchronize()
+        g_big = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_big):
+            big_pass()
+        for _ in range(3):
+            g_big.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(40):
+            g_big.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        big_us = e0.elapsed_time(e1) * 1e3 / (40 * nb)
+        big_bytes = BK * BN // 2 + (BK // GROUP) * BN // 2 + (BK // GROUP) * BN * 2 + BK * 2 + BN * 2
+        big = {"shape": f"M=1 K={BK} N={BN} g={GROUP}", "us_per_launch": round(big_us, 2), "GBps": round(big_bytes / big_us / 1e3, 1),
+               "frac_of_8TBps": round(big_bytes / big_us / 1e3 / HBM_PEAK_GBPS, 4)}
+        del packs
+
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -278,6 +316,7 @@ def main():
                    "weight_sets": sets, "graph_replay": use_graph, "parallelism": f"tp{world}",
                    "tflops": round(world * flops_step * args.steps / wall / 1e12, 3),
                    "weight_layout": "MFMA-fragment-major copy made once at load (awq_repack); checkpoint tensors kept",
+                   "same_kernel_large_matrix": big,
                    "awq_gemm_op_checkpoint_layout": None if op_us is None else {
                        "us_per_launch": round(op_us, 3), "GBps": round(algorithmic_bytes(M) / op_us / 1e3, 1),
                        "frac_of_8TBps": round(algorithmic_bytes(M) / op_us / 1e3 / HBM_PEAK_GBPS, 4),
