@@ -8,6 +8,7 @@
 #ifndef AWQ_AUX_H_
 #define AWQ_AUX_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -23,10 +24,14 @@ int awq_aux_rope_kv(void* qkv, const int64_t* pos, const float* cos_table, const
 
 /* RoPE + KV-cache write + attention of ONE new token per sequence, in one launch (models/llama.py:188-199: rotary_emb, then
  * RadixAttention decode).  qkv[B, (Hq + 2 Hkv) D] is read only; k, v of the token are stored at pos[b] (which must be < S) and
- * out[B, Hq D] = softmax(scale q K^T) V over cache slots 0..pos[b].  D in {64, 128}, Hq % Hkv == 0. */
+ * out[B, Hq D] = softmax(scale q K^T) V over cache slots 0..pos[b].  D in {64, 128}, Hq % Hkv == 0.
+ * num_splits (1..16) workgroups share each (sequence, head), splitting the context ("flash-decoding"; use > 1 when B * Hq is
+ * well below the 256 CUs and the context is long); it needs `workspace` of awq_aux_decode_attention_workspace_bytes(...) bytes,
+ * 16-byte aligned, zero-filled ONCE at allocation (tickets; every call leaves them zero), one per stream of execution. */
+size_t awq_aux_decode_attention_workspace_bytes(int64_t B, int64_t Hq, int64_t D, int num_splits);
 int awq_aux_decode_attention(const void* qkv, const int64_t* pos, const float* cos_table, const float* sin_table, void* k_cache,
                              void* v_cache, void* out, int64_t B, int64_t Hq, int64_t Hkv, int64_t D, int64_t S, float scale,
-                             void* stream);
+                             int num_splits, void* workspace, size_t workspace_bytes, void* stream);
 
 /* act[rows, I] = silu(gate_up[:, :I]) * gate_up[:, I:]   (layers/activation.py SiluAndMul) */
 int awq_aux_silu_mul(const void* gate_up, void* act, int64_t rows, int64_t I, void* stream);

@@ -37,16 +37,36 @@ def rope_kv(qkv: torch.Tensor, pos: torch.Tensor, cos_table: torch.Tensor, sin_t
     _lib.check(rc, "awq_aux_rope_kv")
 
 
+_attn_ws = {}
+
+
+def _attention_workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
+    """Per-device scratch of the split-S attention (tickets + partials); zero-filled once, every call leaves the tickets zero.
+    Allocate it outside graph capture (the first, uncaptured call of a shape does)."""
+    ws = _attn_ws.get(dev.index)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        _attn_ws[dev.index] = ws
+    return ws
+
+
 def decode_attention(qkv: torch.Tensor, pos: torch.Tensor, cos_table: torch.Tensor, sin_table: torch.Tensor, k_cache: torch.Tensor,
-                     v_cache: torch.Tensor, num_heads: int, num_kv_heads: int, head_dim: int) -> torch.Tensor:
+                     v_cache: torch.Tensor, num_heads: int, num_kv_heads: int, head_dim: int, num_splits: int = 1) -> torch.Tensor:
     """RoPE + KV-cache write + one-token attention in one launch; qkv [B, (Hq + 2 Hkv) D] is not modified.
+    num_splits > 1 spreads each (sequence, head) over that many workgroups (long contexts at small batch).
     Returns [B, Hq * D]."""
     assert qkv.dtype == torch.float16 and qkv.is_contiguous() and pos.dtype == torch.int64
     assert k_cache.is_contiguous() and v_cache.is_contiguous() and cos_table.dtype == torch.float32
-    out = torch.empty((qkv.shape[0], num_heads * head_dim), dtype=torch.float16, device=qkv.device)
-    rc = _lib.load().awq_aux_decode_attention(_vp(qkv), _vp(pos), _vp(cos_table), _vp(sin_table), _vp(k_cache), _vp(v_cache), _vp(out),
-                                              qkv.shape[0], num_heads, num_kv_heads, head_dim, k_cache.shape[2],
-                                              float(head_dim) ** -0.5, _stream(qkv))
+    lib = _lib.load()
+    B = qkv.shape[0]
+    out = torch.empty((B, num_heads * head_dim), dtype=torch.float16, device=qkv.device)
+    ws, ws_bytes = None, 0
+    if num_splits > 1:
+        ws_bytes = lib.awq_aux_decode_attention_workspace_bytes(B, num_heads, head_dim, num_splits)
+        ws = _attention_workspace(qkv.device, ws_bytes)
+    rc = lib.awq_aux_decode_attention(_vp(qkv), _vp(pos), _vp(cos_table), _vp(sin_table), _vp(k_cache), _vp(v_cache), _vp(out),
+                                      B, num_heads, num_kv_heads, head_dim, k_cache.shape[2], float(head_dim) ** -0.5,
+                                      int(num_splits), _vp(ws), ws_bytes, _stream(qkv))
     _lib.check(rc, "awq_aux_decode_attention")
     return out
 

@@ -89,6 +89,7 @@ class LlamaDecoderLayer(torch.nn.Module):
         self.register_buffer("v_cache", torch.zeros(max_batch, self.num_kv_heads, max_seq, self.head_dim, dtype=dtype), persistent=False)
 
     FUSE_NORM_MAX_BATCH = 4
+    attn_splits = 1            # workgroups per (sequence, head) in the decode attention; GraphedDecoder sets it from batch / context
 
     @staticmethod
     def _awq_dims(lin):
@@ -130,7 +131,7 @@ class LlamaDecoderLayer(torch.nn.Module):
             x = aux_ops.add_rmsnorm(h, delta, self.input_layernorm, eps)          # h += delta in place
             qkv, _ = self.qkv_proj(x)
         attn = aux_ops.decode_attention(qkv, pos, cos_table, sin_table, self.k_cache, self.v_cache, self.num_heads, self.num_kv_heads,
-                                        self.head_dim)
+                                        self.head_dim, num_splits=self.attn_splits)
         o, _ = self.o_proj(attn.reshape(B, self.q_size))
         act = None
         gu_il = self._gate_up_interleaved() if B <= 32 else None
@@ -247,9 +248,20 @@ class GraphedDecoder:
     def __init__(self, model: LlamaForCausalLM, batch: int, start_pos: int = 0):
         self.model, self.batch = model, batch
         dev = model.embed_tokens.device
+        self.start_pos = start_pos
         self.tokens = torch.zeros(batch, dtype=torch.int64, device=dev)
         self.pos = torch.full((batch,), start_pos, dtype=torch.int64, device=dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
+
+    def _set_attention_splits(self):
+        """Long context at small batch: one workgroup per (sequence, head) leaves most of the chip idle (batch 1, context
+        1024: 16 us per layer); spread each over up to 16 workgroups until the grid covers the 256 CUs."""
+        layer = self.model.layers[0]
+        splits = 1
+        if self.start_pos >= 384:
+            splits = max(1, min(16, 256 // max(1, self.batch * layer.num_heads)))
+        for lyr in self.model.layers:
+            lyr.attn_splits = splits
 
     def _step(self):
         nxt = self.model.step(self.tokens, self.pos)
@@ -258,6 +270,7 @@ class GraphedDecoder:
 
     @torch.no_grad()
     def capture(self, warmup: int = 2):
+        self._set_attention_splits()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):

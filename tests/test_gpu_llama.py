@@ -131,6 +131,13 @@ def test_decode_attention_kernel_vs_fp32_reference(D, Hq, Hkv):
 
     out = aux_ops.decode_attention(qkv, pos, cos_t, sin_t, kc, vc, Hq, Hkv, D)
     torch.cuda.synchronize()
+    # split-S: same result up to fp32 summation order, identical cache writes, tickets left at zero (second call works)
+    for splits in (2, 5, 16):
+        kc2, vc2 = kc0.clone(), vc0.clone()
+        for rep in range(2):
+            out_s = aux_ops.decode_attention(qkv, pos, cos_t, sin_t, kc2, vc2, Hq, Hkv, D, num_splits=splits)
+            assert (out_s.float() - out.float()).abs().max().item() <= 2e-3, f"splits={splits} rep={rep}"
+        assert torch.equal(kc2.view(torch.int16), kc.view(torch.int16)) and torch.equal(vc2.view(torch.int16), vc.view(torch.int16))
     assert torch.equal(qkv, qkv0)                                    # input not modified
 
     def rope(x, c, s):

@@ -92,9 +92,16 @@ def test_aux_argument_validation_without_gpu(lib):
     assert f(h=vp(p), delta=vp(p), w=vp(p), h_out=vp(p), silu=0) == -7             # h_out aliases h
     assert f(M=16, h=vp(p), delta=vp(p), w=vp(p), h_out=vp(p + 64), silu=0) == -7  # too many rows for the prologue
     assert f(K=16384, ldx=16384, h=vp(p), delta=vp(p), w=vp(p), h_out=vp(p + 64), silu=0) == -7   # > 4 k-blocks per wave
-    assert lib.awq_aux_decode_attention(None, vp(p), vp(p), vp(p), vp(p), vp(p), vp(p), 1, 8, 8, 128, 64, 1.0, None) == -1
-    assert lib.awq_aux_decode_attention(vp(p), vp(p), vp(p), vp(p), vp(p), vp(p), vp(p), 1, 8, 3, 128, 64, 1.0, None) == -2    # Hq % Hkv
-    assert lib.awq_aux_decode_attention(vp(p), vp(p), vp(p), vp(p), vp(p), vp(p), vp(p), 1, 8, 8, 96, 64, 1.0, None) == -2     # head dim
+    att = lambda **kw: lib.awq_aux_decode_attention(kw.get("qkv", vp(p)), vp(p), vp(p), vp(p), vp(p), vp(p), vp(p), 1, 8, kw.get("hkv", 8),
+                                                    kw.get("D", 128), 64, 1.0, kw.get("splits", 1), kw.get("ws", None), kw.get("wsb", 0), None)
+    assert att(qkv=None) == -1
+    assert att(hkv=3) == -2                                            # Hq % Hkv
+    assert att(D=96) == -2                                             # head dim
+    assert att(splits=0) == -2 and att(splits=17) == -2
+    assert att(splits=4) == -5                                         # split-S without workspace
+    need = lib.awq_aux_decode_attention_workspace_bytes(1, 8, 128, 4)
+    assert need >= 8 * 4 + 8 * 4 * 130 * 4 and lib.awq_aux_decode_attention_workspace_bytes(1, 8, 128, 1) == 0
+    assert att(splits=4, ws=vp(p), wsb=need - 1) == -5
     assert lib.awq_aux_add_rmsnorm(vp(p), None, vp(p), vp(p), 1, 100, 1e-5, None) == -2      # H % 8
     assert lib.awq_aux_silu_mul(vp(p), None, 1, 64, None) == -1
 
