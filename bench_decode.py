@@ -9,7 +9,7 @@ benchmarks `--load-format dummy` the same way).  Prints one JSON line per batch 
 summary line; `--cpu-seconds` bounds the CPU baseline (the reference's eager-torch CPU dequantise +
 matmul, timed on ONE decoder layer's four linears and scaled by the layer count).
 
-    python bench_decode.py [--model 7b] [--batches 1,2,4,8,16,32] [--steps 64] [--context 128]
+    python bench_decode.py [--model 7b] [--batches 1,2,4,8,16,32] [--steps 64] [--context 1024]
 """
 import argparse
 import json
@@ -28,7 +28,8 @@ def main():
     ap.add_argument("--model", default="7b", choices=["7b", "tiny"])
     ap.add_argument("--batches", default="1,2,4,8,16,32")
     ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--context", type=int, default=128, help="KV positions already in the cache when timing starts")
+    ap.add_argument("--context", type=int, default=1024,
+                    help="KV positions already in the cache when timing starts (bench_one_batch.py defaults to 1024 input tokens)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
 
