@@ -38,6 +38,7 @@ def rope_kv(qkv: torch.Tensor, pos: torch.Tensor, cos_table: torch.Tensor, sin_t
 
 
 _attn_ws = {}
+_attn_ws_retired = []
 
 
 def _attention_workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
@@ -45,7 +46,9 @@ def _attention_workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
     Allocate it outside graph capture (the first, uncaptured call of a shape does)."""
     ws = _attn_ws.get(dev.index)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        if ws is not None:
+            _attn_ws_retired.append(ws)          # a captured graph may still point at it
+        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
         _attn_ws[dev.index] = ws
     return ws
 
