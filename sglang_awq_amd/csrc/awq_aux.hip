@@ -106,41 +106,27 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const half_t* __r
   half_t* kbase = kc + ((size_t)b * Hkv + kvh) * (size_t)S * D;
   half_t* vbase = vc + ((size_t)b * Hkv + kvh) * (size_t)S * D;
 
-  // Split-S ("flash-decoding"): gridDim.z workgroups share one (sequence, head); split sp takes positions
-  // [sp * chunk, (sp + 1) * chunk) of 0 .. pos, chunk = max(64, ceil((pos + 1) / splits)); each leaves an unnormalised
-  // (max, sum, weighted V) partial in the workspace with write-through stores and the last one to arrive merges them in
-  // split order (the ticket hand-off of awq_gemm_skinny.hip: no fences, deterministic).  One workgroup per head leaves
-  // 7/8 of the chip idle at batch 1: 16 us per layer at context 1024, 44 us at 4096.
+  // Split-S ("flash-decoding"): gridDim.z workgroups share one (sequence, head); the context is cut into blocks of
+  // BLK = 4 * NPG positions dealt round-robin (split sp takes blocks sp, sp + splits, ...), so the first block of every
+  // split has an address that does not depend on pos.  Each split leaves an unnormalised (max, sum, weighted V) partial
+  // in the workspace with write-through stores and the last one to arrive merges them in split order (the ticket
+  // hand-off of awq_gemm_skinny.hip: no fences, deterministic).  One workgroup per head leaves 7/8 of the chip idle at
+  // batch 1: 16 us per layer at context 1024, 44 us at 4096.
+  constexpr int BLK = U * NPG;
   const int ns = (int)gridDim.z, sp = (int)blockIdx.z;
 
-  // block 0 of K / V: for split 0 the addresses do not depend on pos (rows < S exist; what lies past pos is masked
-  // below); the other splits learn their range from pos first
+  // first block of K / V, requested before pos is known (rows < S exist; what lies past pos is masked below)
   half8v kv[U], vv[U];
-  if (sp == 0) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int j = pg + u * NPG;
-      const int jc = j < S ? j : S - 1;
-      kv[u] = *(const half8v*)(kbase + (size_t)jc * D + lp * 8);
-      vv[u] = *(const half8v*)(vbase + (size_t)jc * D + lp * 8);
-    }
+  for (int u = 0; u < U; ++u) {
+    const int j = sp * BLK + pg + u * NPG;
+    const int jc = j < S ? j : S - 1;
+    kv[u] = *(const half8v*)(kbase + (size_t)jc * D + lp * 8);
+    vv[u] = *(const half8v*)(vbase + (size_t)jc * D + lp * 8);
   }
 
   const int p = (int)pos[b];                                        // cached positions 0 .. p-1, the new token is p
-  int chunk = (p + ns) / ns;                                         // ceil((p + 1) / ns)
-  if (chunk < 64) chunk = 64;
-  const int j_lo = sp * chunk;
-  const int j_hi = j_lo + chunk - 1 < p ? j_lo + chunk - 1 : p;      // inclusive; empty split if j_lo > p
-  const bool has_new = j_lo <= p && p <= j_hi;                       // this split handles the new token
-  if (sp != 0 && j_lo <= p) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int j = j_lo + pg + u * NPG;
-      const int jc = j < p ? j : (p > 0 ? p - 1 : 0);
-      kv[u] = *(const half8v*)(kbase + (size_t)jc * D + lp * 8);
-      vv[u] = *(const half8v*)(vbase + (size_t)jc * D + lp * 8);
-    }
-  }
+  const bool has_new = (p / BLK) % ns == sp;                         // the split whose block holds the new token stores it
   const half_t* row = qkv + (size_t)b * (Hq + 2 * Hkv) * D;
   if (t < HALF) {                                                    // q: rotate, round to fp16 as the unfused path does, pre-scale
     const float c = cos_t[(size_t)p * HALF + t], sn = sin_t[(size_t)p * HALF + t];
@@ -179,13 +165,14 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const half_t* __r
 
   float m = -INFINITY, l = 0.f;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int j0 = j_lo + pg; j0 <= j_hi; j0 += U * NPG) {
-    half8v kn[U], vn[U];                                             // next block, requested before this one is reduced
-    const bool more = j0 + U * NPG <= j_hi;
+  for (int jb = sp * BLK; jb <= p; jb += ns * BLK) {
+    const int j0 = jb + pg;
+    half8v kn[U], vn[U];                                             // this split's next block, requested before this one is reduced
+    const bool more = jb + ns * BLK <= p;
     if (more) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int j = j0 + (U + u) * NPG;
+        const int j = j0 + ns * BLK + u * NPG;
         const int jc = j < p ? j : (p > 0 ? p - 1 : 0);
         kn[u] = *(const half8v*)(kbase + (size_t)jc * D + lp * 8);
         vn[u] = *(const half8v*)(vbase + (size_t)jc * D + lp * 8);
@@ -202,17 +189,18 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const half_t* __r
       for (int e = 0; e < 8; ++e) d += qf[e] * (float)k8[e];
 #pragma unroll
       for (int o = LP / 2; o > 0; o >>= 1) d += __shfl_xor(d, o);
-      sc[u] = j <= j_hi ? d : -INFINITY;
+      sc[u] = j <= p ? d : -INFINITY;
       bm = fmaxf(bm, sc[u]);
     }
-    const float corr = __expf(m - bm);                               // first block: exp(-inf) = 0 (bm is finite: j0 <= j_hi)
+    // (a group whose four positions all lie past pos keeps bm = m; with m = -inf that is exp(-inf - -inf): guard it)
+    const float corr = bm == -INFINITY ? 0.f : __expf(m - bm);
     l *= corr;
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] *= corr;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int j = j0 + u * NPG;
-      if (j <= j_hi) {                                               // rows past the range may hold anything (even NaN): never touch them
+      if (j <= p) {                                                  // rows past pos may hold anything (even NaN): never touch them
         const half8v v8 = j == p ? vnew : vv[u];
         const float w = __expf(sc[u] - bm);
         l += w;
