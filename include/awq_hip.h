@@ -77,7 +77,7 @@ int awq_dequantize(const int32_t* qweight, const void* scales, const int32_t* qz
  *   workspace: device scratch of at least awq_gemm_workspace_bytes(...) bytes, 16-byte aligned,
  *   zero-filled ONCE when allocated (arrival counters live in it and every call leaves them
  *   zero again).  It may be shared by successive calls on one stream, not by concurrent streams.
- *   For prefill-sized M (>= 1024, fp16, K % 128 == 0, g % 128 == 0) awq_gemm_workspace_bytes() also
+ *   For M > 32 (fp16, K % 128 == 0, g % 128 == 0) awq_gemm_workspace_bytes() also
  *   covers one re-laid-out copy of the weight: the call then repacks on the fly and runs the kernel
  *   of awq_gemm_repacked; with less workspace it keeps to the checkpoint-layout kernels.
  *   bias (may be NULL): [N] in `dtype`, added AFTER the sum is rounded to `dtype`, with a second

@@ -84,10 +84,11 @@ int awq_dequantize(const int32_t* qweight, const void* scales, const int32_t* qz
   return launch_dequantize(qweight, scales, qzeros, out, K, N, group_size, dtype, (hipStream_t)stream);
 }
 
-// Prefill-sized calls of the op re-lay the weight out on the fly: one pass over the packed weight into the workspace
-// (awq_repack, ~40 us at 4096 x 11008) buys the hand-pipelined kernel of the fragment-major layout (191 us at
-// M = 2048) instead of the checkpoint-layout tiles (311 us); below ~800 rows the pass costs more than it saves.
-constexpr int64_t kRepackOnTheFlyMinM = 1024;
+// Calls of the op beyond the decode range re-lay the weight out on the fly: one pass over the packed weight into the
+// workspace (awq_repack, ~17 us at 4096 x 11008) buys the kernels of the fragment-major layout.  Measured against the
+// checkpoint-layout kernels (11008 x 4096: M = 64 212 -> 63 us, M = 256 217 -> 118, M = 2048 311 -> 225; 4096 x 11008:
+// M = 128 85 -> 61, M = 512 104 -> 89) it wins from the first row count the split-K decode kernel does not cover.
+constexpr int64_t kRepackOnTheFlyMinM = 33;
 constexpr size_t kWorkspaceHead = 4096;        // arrival counters of the split-K kernel live here
 
 size_t awq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t group_size, int dtype) {
@@ -125,6 +126,13 @@ int awq_gemm_ex(const void* x, int64_t ldx, const int32_t* qweight, const void* 
     if (!workspace || workspace_bytes < awq_gemm_workspace_bytes(M, K, N, group_size, dtype)) return AWQ_ERR_WORKSPACE;
     return launch_gemm_skinny(a);
   }
+  if (M >= kRepackOnTheFlyMinM && repacked_supported(K, N, group_size, dtype) && workspace && (((uintptr_t)workspace) & 15) == 0 &&
+      workspace_bytes >= kWorkspaceHead + repacked_bytes(K, N, group_size) && a.ldx % 8 == 0 && (((uintptr_t)x) & 15) == 0) {
+    void* packed = (char*)workspace + kWorkspaceHead;
+    rc = launch_repack(qweight, scales, qzeros, packed, K, N, group_size, dtype, a.stream);
+    if (rc) return rc;
+    return repacked_dispatch(a, packed);
+  }
   // 16 < M <= 48: the 128-row tiles of the prefill kernel would leave most CUs idle (N / 128 workgroups);
   // two or three passes of the decode kernel over 16-row slabs of x are faster (measured 82 us tiled vs
   // ~20 us per pass at 4096 x 11008).  Passes are stream-ordered, so they can share the workspace.
@@ -142,13 +150,6 @@ int awq_gemm_ex(const void* x, int64_t ldx, const int32_t* qweight, const void* 
       }
       return AWQ_OK;
     }
-  }
-  if (M >= kRepackOnTheFlyMinM && repacked_supported(K, N, group_size, dtype) && workspace && (((uintptr_t)workspace) & 15) == 0 &&
-      workspace_bytes >= kWorkspaceHead + repacked_bytes(K, N, group_size) && a.ldx % 8 == 0 && (((uintptr_t)x) & 15) == 0) {
-    void* packed = (char*)workspace + kWorkspaceHead;
-    rc = launch_repack(qweight, scales, qzeros, packed, K, N, group_size, dtype, a.stream);
-    if (rc) return rc;
-    return repacked_dispatch(a, packed);
   }
   if (tiled_supported(a)) return launch_gemm_tiled(a);
   return launch_gemm_generic(a);

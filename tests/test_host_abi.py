@@ -109,11 +109,12 @@ def test_aux_argument_validation_without_gpu(lib):
 def test_workspace_query(lib):
     small = lib.awq_gemm_workspace_bytes(1, 4096, 11008, 128, 0)
     assert 4096 <= small <= 4096 + (32 << 20)
-    # prefill-sized fp16 calls: room for the on-the-fly re-layout (head + one repacked copy); bf16 / g = 64 keep the slab size
+    # fp16 calls beyond the decode range: room for the on-the-fly re-layout (head + one repacked copy); bf16 / g = 64 keep the slab size
     assert lib.awq_gemm_workspace_bytes(2048, 4096, 11008, 128, 0) == 4096 + lib.awq_repacked_bytes(4096, 11008, 128, 0)
     assert lib.awq_gemm_workspace_bytes(2048, 4096, 11008, 128, 1) <= 4096 + (32 << 20)
     assert lib.awq_gemm_workspace_bytes(2048, 4096, 11008, 64, 0) <= 4096 + (32 << 20)
-    assert lib.awq_gemm_workspace_bytes(512, 4096, 11008, 128, 0) <= 4096 + (32 << 20)
+    assert lib.awq_gemm_workspace_bytes(64, 4096, 11008, 128, 0) == 4096 + lib.awq_repacked_bytes(4096, 11008, 128, 0)
+    assert lib.awq_gemm_workspace_bytes(32, 4096, 11008, 128, 0) <= 4096 + (32 << 20)
     assert lib.awq_gemm_workspace_bytes(0, 0, 0, 128, 0) >= 0
 
 
