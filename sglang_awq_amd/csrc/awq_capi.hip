@@ -31,7 +31,7 @@ static int repacked_dispatch(const GemmArgs& a, const void* packed) {
   // <= 32 rows: the streaming GEMV.  Up to 160 rows, passes of it (32 rows each) beat the 128 x 256 MFMA tiles, which
   // would leave most CUs idle (4096 x 11008: 13.6 us per pass vs ~62 us for one round of under-filled tiles).  Where the
   // wide tiles are few (narrow matrices, up to 512 rows) 128 x 64 tiles with the K split inside the workgroup fill the
-  // chip better (11008 x 4096 at M = 256: 142 -> 100 us); beyond that the hand-pipelined wide tiles.
+  // chip better (11008 x 4096 at M = 256: 142 -> 90 us); beyond that the hand-pipelined wide tiles.
   static const int env_mid = getenv("AWQ_MID") ? atoi(getenv("AWQ_MID")) : 1;      // A/B knob: 0 = never the 128 x 64 tiles
   if (M <= 32) return launch_gemv_repacked(a, packed);
   const bool aligned = a.ldx % 8 == 0 && (((uintptr_t)a.x) & 15) == 0;

@@ -237,10 +237,10 @@ int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed) {
 // k = 32 w .. 32 w + 31 of each block: dword w of the fragment-major dwordx4), so a wave still reuses each dequantised
 // fragment for 8 row tiles; the four partial tiles are summed in fixed order through LDS at the end (no workspace,
 // deterministic).  Four times the workgroups of the wide tile, the weight streamed once.
-// Compiler-scheduled (accumulators tied in AGPRs); a K block is ~1 us here against ~0.35 us of MFMA work (removing
-// the x loads, the LDS staging and the barrier together only brings 48 us down to 33 at M = 128, 4096 x 11008: the
-// dequantise -> MFMA chain of one wave per SIMD is the cost), so it is dispatched only where it measured faster than
-// the alternatives: 11008 x 4096 at M = 256 / 512: 142 -> 100 / 108 us; 4096 x 11008 at M = 128: 54 -> 41 us.
+// Hand-pipelined like the 128 x 256 kernel.  Still ~1.1 us per K block against ~0.35 us of MFMA work (the compiler-scheduled
+// form: 1.25 us; removing its x loads, LDS staging and barrier together only brought 48 us down to 33 at M = 128,
+// 4096 x 11008), so it is dispatched only where it measured faster than the alternatives: 11008 x 4096 at M = 256 / 512:
+// 142 -> 90 / 97 us; 4096 x 11008 at M = 128: 54 -> 40 us.
 __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_ksplit_kernel(const uint16_t* __restrict__ x, int64_t ldx,
                                                                              const uint32_t* __restrict__ qw_r,
                                                                              const uint32_t* __restrict__ zs_r,
@@ -305,42 +305,82 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_ksplit_kernel(con
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[mi][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
-  // tile t travels in a_st[t & 1], is written to LDS buffer t & 1 at the end of step t - 1 and consumed in step t
+  // Tile t travels in a_st[t & 1], is written to LDS buffer t & 1 during step t - 1 and consumed in step t; the weights of
+  // block t sit in w_buf[t & 1] until step t - 1 has turned them into fragments.  One step = 32 MFMAs per wave (4 fragments
+  // x 8 row tiles); behind each MFMA rides one of the 28 dequantise stages of the NEXT block's four fragments (as in the
+  // 128 x 256 kernel above), the eight LDS writes of the next x tile ride in j = 1, the one barrier per block sits after
+  // them, and the next block's x fragments are fetched behind it during j = 3 — no LDS or load latency at the block boundary.
   load_a(a_st[0], 0);
   load_b(w_buf[0], zs_buf[0], 0);
   load_b(w_buf[1], zs_buf[1], KB > 1 ? 1 : 0);
   store_a(a_st[0], 0);
   load_a(a_st[1], KB > 1 ? 1 : 0);
+  u32x4_t frag[4], frag_n[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const ZsU u = zs_unpack(zs_buf[0][j]);
+    frag[j] = rp_dequant(w_buf[0][j], u.z1024, u.z64, u.s2);
+  }
   __syncthreads();
+  u32x4_t af[MI], af_n[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) af[mi] = *(const u32x4_t*)(As + pfp_off(mi * 16 + r, wave * 4 + q));
 
   auto step = [&](auto P_, int kb) {
     constexpr int P = decltype(P_)::value;
     const int k2 = kb + 2 < KB ? kb + 2 : KB - 1;       // clamped, unconditional prefetch
-    uint32_t wv[4], zv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { wv[j] = w_buf[P][j]; zv[j] = zs_buf[P][j]; }
-    load_a(a_st[P], k2);                                 // (tile kb already sits in LDS buffer P)
-    load_b(w_buf[P], zs_buf[P], k2);
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned char* Ab = As + P * (kPfBM * 256);
-    u32x4_t af[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) af[mi] = *(const u32x4_t*)(Ab + pfp_off(mi * 16 + r, wave * 4 + q));
+    // block kb + 1's weights (requested two steps ago) become this step's passengers; block kb's registers are free again
+    uint32_t wn[4];
+    ZsU zn[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const ZsU u = zs_unpack(zv[j]);
-      const u32x4_t frag = rp_dequant(wv[j], u.z1024, u.z64, u.s2);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) mfma_tied(acc[mi][j], af[mi], frag);
+      wn[j] = w_buf[P ^ 1][j];
+      uint32_t z = zs_buf[P ^ 1][j];
+      pin_here(wn[j]);
+      pin_here(z);
+      zn[j] = zs_unpack(z);
     }
+    load_a(a_st[P], k2);                                 // (tile kb already sits in LDS buffer P, its fragments in af)
+    load_b(w_buf[P], zs_buf[P], k2);
     __builtin_amdgcn_sched_barrier(0);
-    store_a(a_st[P ^ 1], P ^ 1);                         // tile kb + 1, requested a full step ago; nobody reads that buffer until the barrier
-    __syncthreads();
+    const unsigned char* An = As + (P ^ 1) * (kPfBM * 256);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      DqPipe pp;
+      pp.w = wn[j];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        mfma_tied(acc[mi][j], af[mi], frag[j]);
+        switch (mi) {                                    // (compile-time after unrolling)
+          case 0: dq_stage<0>(pp, zn[j].z1024, zn[j].z64, zn[j].s2); break;
+          case 1: dq_stage<1>(pp, zn[j].z1024, zn[j].z64, zn[j].s2); break;
+          case 2: dq_stage<2>(pp, zn[j].z1024, zn[j].z64, zn[j].s2); break;
+          case 3: dq_stage<3>(pp, zn[j].z1024, zn[j].z64, zn[j].s2); break;
+          case 4: dq_stage<4>(pp, zn[j].z1024, zn[j].z64, zn[j].s2); break;
+          case 5: dq_stage<5>(pp, zn[j].z1024, zn[j].z64, zn[j].s2); break;
+          case 6: dq_stage<6>(pp, zn[j].z1024, zn[j].z64, zn[j].s2); break;
+          default: break;
+        }
+        if (j == 1) {                                    // tile kb + 1 (requested a full step ago) -> the other LDS buffer
+          const int c = tid + kPfThreads * mi;
+          *(u32x4_t*)(As + (P ^ 1) * (kPfBM * 256) + pfp_off(c >> 4, c & 15)) = a_st[P ^ 1][mi];
+        }
+        if (j == 2 && mi == 7) __syncthreads();
+        if (j == 3) af_n[mi] = *(const u32x4_t*)(An + pfp_off(mi * 16 + r, wave * 4 + q));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      frag_n[j] = pp.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) frag[j] = frag_n[j];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) af[mi] = af_n[mi];
   };
   for (int kb = 0; kb < KB; kb += 2) {
     step(std::integral_constant<int, 0>{}, kb);
     if (kb + 1 < KB) step(std::integral_constant<int, 1>{}, kb + 1);
   }
+  __syncthreads();                                       // every wave is done with the x buffers: they become the reduction scratch
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the last MFMAs' results must have left the pipe before the reads below
 
   // partial tiles -> LDS [wave][mi][j][i][lane] (conflict-free: consecutive lanes, consecutive floats), summed in wave order
