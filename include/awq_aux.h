@@ -33,6 +33,9 @@ int awq_aux_decode_attention(const void* qkv, const int64_t* pos, const float* c
                              void* v_cache, void* out, int64_t B, int64_t Hq, int64_t Hkv, int64_t D, int64_t S, float scale,
                              int num_splits, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Greedy sampling tail of a decode step: tokens[b] = argmax(logits[b, :V]) (first maximum, fp16 logits, V % 8 == 0), pos[b] += 1. */
+int awq_aux_argmax_advance(const void* logits, int64_t* tokens, int64_t* pos, int64_t B, int64_t V, void* stream);
+
 /* act[rows, I] = silu(gate_up[:, :I]) * gate_up[:, I:]   (layers/activation.py SiluAndMul) */
 int awq_aux_silu_mul(const void* gate_up, void* act, int64_t rows, int64_t I, void* stream);
 

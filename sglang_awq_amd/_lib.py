@@ -29,7 +29,7 @@ EXPORTS = (
 )
 # include/awq_aux.h (decode-harness helpers, not part of the operator boundary)
 AUX_EXPORTS = ("awq_aux_add_rmsnorm", "awq_aux_rope_kv", "awq_aux_decode_attention", "awq_aux_decode_attention_workspace_bytes",
-               "awq_aux_silu_mul",
+               "awq_aux_argmax_advance", "awq_aux_silu_mul",
                "awq_aux_gemv_repacked_fused")
 ABI_VERSION = 1
 
@@ -87,6 +87,8 @@ def _bind(L):
     L.awq_aux_decode_attention.restype = ci
     L.awq_aux_gemv_repacked_fused.argtypes = [vp, i64, vp, vp, i64, i64, i64, i64, ci, vp, vp, vp, vp, ctypes.c_float, ci, vp]
     L.awq_aux_gemv_repacked_fused.restype = ci
+    L.awq_aux_argmax_advance.argtypes = [vp, vp, vp, i64, i64, vp]
+    L.awq_aux_argmax_advance.restype = ci
     L.awq_aux_silu_mul.argtypes = [vp, vp, i64, i64, vp]
     L.awq_aux_silu_mul.restype = ci
 

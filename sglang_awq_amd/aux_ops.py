@@ -74,6 +74,14 @@ def decode_attention(qkv: torch.Tensor, pos: torch.Tensor, cos_table: torch.Tens
     return out
 
 
+def argmax_advance(logits: torch.Tensor, tokens: torch.Tensor, pos: torch.Tensor) -> None:
+    """tokens[b] = argmax(logits[b]) (first maximum), pos[b] += 1, in one launch (the greedy tail of a decode step)."""
+    assert logits.dtype == torch.float16 and logits.dim() == 2 and logits.is_contiguous()
+    assert tokens.dtype == torch.int64 and pos.dtype == torch.int64 and tokens.is_contiguous() and pos.is_contiguous()
+    rc = _lib.load().awq_aux_argmax_advance(_vp(logits), _vp(tokens), _vp(pos), logits.shape[0], logits.shape[1], _stream(logits))
+    _lib.check(rc, "awq_aux_argmax_advance")
+
+
 def silu_mul(gate_up: torch.Tensor) -> torch.Tensor:
     assert gate_up.dtype == torch.float16 and gate_up.is_contiguous() and gate_up.dim() == 2
     inter = gate_up.shape[1] // 2

@@ -294,6 +294,47 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const half_t* __restrict_
   }
 }
 
+// Greedy sampling tail of a decode step in one launch: tokens[b] = argmax(logits[b, :]) (first maximum, as torch.argmax),
+// pos[b] += 1.  One workgroup per sequence; replaces a reduce kernel + a copy + an add (three dependent tiny launches).
+__global__ __launch_bounds__(1024) void argmax_advance_kernel(const half_t* __restrict__ logits, int64_t* __restrict__ tokens,
+                                                              int64_t* __restrict__ pos, int V) {
+  __shared__ float bv[16];
+  __shared__ int bi[16];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const half_t* row = logits + (size_t)b * V;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int i = t * 8; i < V; i += 1024 * 8) {
+    if (i + 8 <= V) {
+      const half8v v = *(const half8v*)(row + i);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = (float)v[e];
+        if (f > best || (f == best && i + e < idx)) { best = f; idx = i + e; }
+      }
+    } else {
+      for (int e = 0; i + e < V; ++e) {
+        const float f = (float)row[i + e];
+        if (f > best || (f == best && i + e < idx)) { best = f; idx = i + e; }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o);
+    const int oi = __shfl_xor(idx, o);
+    if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+  }
+  if ((t & 63) == 0) { bv[t >> 6] = best; bi[t >> 6] = idx; }
+  __syncthreads();
+  if (t == 0) {
+    for (int w = 1; w < 16; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+    tokens[b] = idx;
+    pos[b] += 1;
+  }
+}
+
 }  // namespace awq
 
 extern "C" {
@@ -340,6 +381,15 @@ int awq_aux_decode_attention(const void* qkv, const int64_t* pos, const float* c
 size_t awq_aux_decode_attention_workspace_bytes(int64_t B, int64_t Hq, int64_t D, int num_splits) {
   if (num_splits <= 1 || B <= 0 || Hq <= 0 || D <= 0) return 0;
   return (((size_t)B * Hq * sizeof(unsigned) + 255) & ~(size_t)255) + (size_t)B * Hq * num_splits * (D + 2) * sizeof(float);
+}
+
+int awq_aux_argmax_advance(const void* logits, int64_t* tokens, int64_t* pos, int64_t B, int64_t V, void* stream) {
+  if (!logits || !tokens || !pos) return AWQ_ERR_NULL_POINTER;
+  if (B <= 0 || V <= 0 || V >= (1ll << 31) || V % 8) return AWQ_ERR_BAD_SHAPE;      // rows of V halves must stay 16-byte aligned
+  if (((uintptr_t)logits) & 15) return AWQ_ERR_MISALIGNED;
+  hipLaunchKernelGGL(awq::argmax_advance_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, (const awq::half_t*)logits, tokens, pos,
+                     (int)V);
+  return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
 int awq_aux_silu_mul(const void* gate_up, void* act, int64_t rows, int64_t I, void* stream) {

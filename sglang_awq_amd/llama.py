@@ -264,7 +264,13 @@ class GraphedDecoder:
             lyr.attn_splits = splits
 
     def _step(self):
-        nxt = self.model.step(self.tokens, self.pos)
+        model = self.model
+        if model.fused_aux and model.dtype == torch.float16 and model.cfg.vocab_size % 8 == 0:
+            from . import aux_ops
+
+            aux_ops.argmax_advance(model.logits(self.tokens, self.pos), self.tokens, self.pos)   # greedy tail in one launch
+            return
+        nxt = model.step(self.tokens, self.pos)
         self.tokens.copy_(nxt)
         self.pos.add_(1)
 

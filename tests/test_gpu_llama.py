@@ -166,3 +166,23 @@ def test_decode_attention_kernel_vs_fp32_reference(D, Hq, Hkv):
         assert err <= 2e-3 + 2e-3 * want.abs().max().item(), f"b={b} pos={p} err={err}"
     assert torch.equal(kc[B], kc0[B]) and torch.equal(vc[B], vc0[B])
     assert torch.isfinite(out).all()
+
+
+def test_argmax_advance_kernel_matches_torch():
+    """Greedy tail of a decode step: first-maximum argmax over fp16 logits (ties, -inf rows, ragged vocabulary) + pos += 1."""
+    from sglang_awq_amd import aux_ops
+
+    torch.manual_seed(5)
+    for V in (32000, 512, 8200):
+        B = 5
+        logits = torch.randn(B, V, device=DEV).half()
+        logits[1, 17] = logits[1].max() + 1
+        logits[1, V - 3] = logits[1, 17]                         # tie: the first index wins
+        logits[2] = float("-inf")
+        logits[2, V - 1] = -1000.0
+        logits[3, :] = 0.5                                        # all equal -> index 0
+        tokens = torch.zeros(B, dtype=torch.int64, device=DEV)
+        pos = torch.arange(B, dtype=torch.int64, device=DEV) * 3
+        aux_ops.argmax_advance(logits, tokens, pos)
+        assert torch.equal(tokens, logits.float().argmax(-1))
+        assert torch.equal(pos, torch.arange(B, device=DEV) * 3 + 1)
