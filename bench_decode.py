@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Llama-2-7B-AWQ decode tok/s, TP=1, batch 1-32 (BASELINE configs[3]) on one MI355X.
+"""Llama-2-7B-AWQ decode tok/s, TP=1, batch 1-32 (BASELINE configs[3]) on one MI355X; `--model 70b` is Llama-2-70B-AWQ
+(configs[4]) — at TP=1 it fits one MI355X (35 GB packed + the repacked copies), and under
+`python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 bench_decode.py --model 70b` it runs TP=N over RCCL.
 
 Method of the reference's bench_one_batch.py (:497-623): per decode step `synchronize; tic; decode;
 synchronize`, report the MEDIAN step latency and batch / latency as tok/s.  The decode step is this
@@ -25,7 +27,7 @@ if ROOT not in sys.path:
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="7b", choices=["7b", "tiny"])
+    ap.add_argument("--model", default="7b", choices=["7b", "70b", "tiny"])
     ap.add_argument("--batches", default="1,2,4,8,16,32")
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--context", type=int, default=1024,
@@ -38,9 +40,20 @@ def main():
     from sglang_awq_amd.awq import AWQConfig
     from sglang_awq_amd.llama import GraphedDecoder, LlamaConfig, LlamaForCausalLM
 
-    dev = torch.device("cuda", 0)
-    cfg = LlamaConfig.llama2_7b() if args.model == "7b" else LlamaConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=4,
-                                                                          num_attention_heads=8, num_key_value_heads=8, vocab_size=2048)
+    from sglang_awq_amd.distributed import init_tensor_parallel
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    init_tensor_parallel(backend="nccl", device=dev) if world > 1 else init_tensor_parallel()
+    if args.model == "7b":
+        cfg = LlamaConfig.llama2_7b()
+    elif args.model == "70b":
+        cfg = LlamaConfig.llama2_70b()
+    else:
+        cfg = LlamaConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=4, num_attention_heads=8, num_key_value_heads=8,
+                          vocab_size=2048)
     batches = [int(b) for b in args.batches.split(",")]
     max_seq = args.context + args.steps + 16
     with torch.device(dev):
@@ -60,7 +73,7 @@ def main():
         for _ in range(args.steps):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            dec.graph.replay()
+            dec.run(1)
             torch.cuda.synchronize()
             lat.append(time.perf_counter() - t0)
         med = statistics.median(lat)
@@ -69,21 +82,23 @@ def main():
         dec.pos.fill_(args.context)
         e0.record()
         for _ in range(16):
-            dec.graph.replay()
+            dec.run(1)
         e1.record()
         torch.cuda.synchronize()
         dev_ms = e0.elapsed_time(e1) / 16
-        r = {"metric": "Llama-2-7B-AWQ decode tok/s TP=1" if args.model == "7b" else "tiny-llama decode tok/s", "batch": B,
+        name = {"7b": "Llama-2-7B-AWQ", "70b": "Llama-2-70B-AWQ", "tiny": "tiny-llama"}[args.model]
+        r = {"metric": f"{name} decode tok/s TP={world}", "batch": B,
              "value": round(B / med, 1), "unit": "tok/s", "median_step_ms": round(med * 1e3, 4), "device_step_ms": round(dev_ms, 4),
              "tok_per_s_device": round(B / (dev_ms * 1e-3), 1), "context": args.context, "steps": args.steps,
              "weight_GB_per_step": round((lin_bytes + head_bytes) / 1e9, 3),
              "hbm_GBps_device": round((lin_bytes + head_bytes) / (dev_ms * 1e-3) / 1e9, 1), "data": "synthetic", "dtype": "f16"}
         results.append(r)
-        print(json.dumps(r), flush=True)
+        if rank == 0:
+            print(json.dumps(r), flush=True)
         del dec
 
     cpu = None
-    if args.cpu_seconds > 0:
+    if args.cpu_seconds > 0 and rank == 0:
         from oracle import torch_cpu
         from sglang_awq_amd import synth
 
@@ -105,7 +120,8 @@ def main():
         cpu = {"value": round(1.0 / (per_layer * cfg.num_hidden_layers), 4), "unit": "tok/s", "cores": torch.get_num_threads(), "kind": "port",
                "sample": f"{n} x the four AWQ linears of ONE decoder layer at batch 1 (eager torch CPU dequantise + matmul), "
                          f"{per_layer * 1e3:.0f} ms per layer, scaled by {cfg.num_hidden_layers} layers; attention / lm_head not counted"}
-    print(json.dumps({"summary": {f"b{r['batch']}": r["value"] for r in results}, "unit": "tok/s", "cpu_baseline": cpu}), flush=True)
+    if rank == 0:
+        print(json.dumps({"summary": {f"b{r['batch']}": r["value"] for r in results}, "unit": "tok/s", "cpu_baseline": cpu}), flush=True)
 
 
 if __name__ == "__main__":

@@ -283,13 +283,22 @@ class GraphedDecoder:
             for _ in range(warmup):
                 self._step()
         torch.cuda.current_stream().wait_stream(s)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._step()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph):
+                self._step()
+            self.graph = graph
+        except Exception as e:       # e.g. a collective that cannot be captured on this stack: run() then steps eagerly
+            import sys
+
+            print(f"GraphedDecoder: graph capture failed ({e!r}); stepping eagerly", file=sys.stderr)
+            self.graph = None
+            torch.cuda.synchronize()
         return self
 
     @torch.no_grad()
     def run(self, steps: int) -> List[int]:
+        """steps decode steps (graph replays, or eager steps when capture was not possible); returns the current tokens."""
         for _ in range(steps):
             if self.graph is not None:
                 self.graph.replay()
