@@ -43,8 +43,8 @@ int awq_aux_silu_mul(const void* gate_up, void* act, int64_t rows, int64_t I, vo
  * neighbours folded in:
  *   norm_h != NULL: x is ignored and x = RMSNorm(norm_h + norm_delta) * norm_w is built in the kernel's prologue;
  *                   norm_h_out = norm_h + norm_delta ([M, K], row stride ldx for all three; must not alias norm_h;
- *                   norm_delta must not be NULL — pass zeros).  M * K <= 32768, K <= 8192.
- *   silu_mul != 0:  `packed` was repacked from tensors whose 16-column groups alternate gate / up
+ *                   norm_delta must not be NULL — pass zeros).  M * K <= 32768, K <= 16384.
+ *   silu_mul != 0:  (alone also for N > 32768, in rounds of narrow strips) `packed` was repacked from tensors whose 16-column groups alternate gate / up
  *                   (column 32 p + r = gate 16 p + r, 32 p + 16 + r = up 16 p + r); y = silu(gate) * up, [M, N / 2].
  * Returns AWQ_ERR_BAD_VARIANT (-7) for a shape without a fused instantiation: run the separate ops instead. */
 int awq_aux_gemv_repacked_fused(const void* x, int64_t ldx, const void* packed, void* y, int64_t M, int64_t K, int64_t N,

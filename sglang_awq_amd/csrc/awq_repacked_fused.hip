@@ -39,6 +39,14 @@ int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed) {
   const int NG = rp_groups(a.N), KB = a.K / 128;
   int G = (NG + 255) / 256;
   if (a.silu_mul && (G & 1)) ++G;
+  if (G > kRpMaxG && a.silu_mul && !norm && a.M <= 16 && (((uintptr_t)a.x) & 15) == 0) {
+    // N > 32768 (e.g. the 57344-wide gate_up of a 70B model): rounds of 4-group strips on 8-wave workgroups, as the plain
+    // launcher does, with the SiLU-mul epilogue (a strip holds two (gate, up) pairs)
+    const int pw = (KB + 7) / 8;
+    const size_t lds_r = (size_t)8 * a.M * 16 * 4 * sizeof(float);
+    rp_launch<4, 8, true, 1, 0, 1>(a, packed, NG, pw, 0, (NG + 3) / 4, lds_r);
+    return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+  }
   if (G > kRpMaxG || G > NG) return AWQ_ERR_BAD_VARIANT;
   const int nwg = (NG + G - 1) / G;
   const int T = (KB + W - 1) / W;                                            // = per_wave: straight-line variants only

@@ -332,10 +332,11 @@ constexpr bool rp_fits(int W, int MT, int G, int T) {
 // The fused variants exist for 16 waves, non-temporal loads, one row tile, T = 1..4.  The norm prologue's x
 // fragments arrive late (from LDS, after the weight loads were issued), so it needs no more registers than the
 // plain kernel (tools/rp_resources.py lists them too).
+constexpr bool rp_fits_xl(int G, int T);
 constexpr bool rp_fits_fused(int G, int T, int PRO, int EPI) {
-  if (T < 1 || T > 4 || (EPI && (G & 1))) return false;
-  if (PRO >= 2 && G == 8 && T == 2) return false;                  // a few bytes of scratch
-  return rp_fits(16, 1, G, T);
+  if (EPI && (G & 1)) return false;
+  if (PRO > 0) return rp_fits_xl(G, T) && !(PRO >= 2 && G == 8 && T == 2);      // x fragments come lazily from LDS: 5 G registers per k-block
+  return T >= 1 && T <= 4 && rp_fits(16, 1, G, T);
 }
 
 // x staged through wave-private LDS (PRO < 0), 16 waves: T k-blocks of 5 G registers each (tools/rp_resources.py)
@@ -351,7 +352,8 @@ static void rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wav
   if constexpr ((PRO == 0 && EPI == 0) ? (TT <= 6 && rp_fits(W, MT, G, TT) && (MT == 1 || TT == 0 || TT == 4))                           \
                 : (PRO < 0)            ? (W == 16 && NT && MT == 1 && !(EPI && (G & 1)) && rp_fits_xl(G, TT))                            \
                 : (MT == 2)            ? (PRO == 0 && W == 8 && NT && !(G & 1) && rp_fits(8, 2, G, TT))   /* SiLU-mul epilogue, 17..32 rows */ \
-                                       : (TT <= 6 && W == 16 && NT && MT == 1 && rp_fits_fused(G, TT, PRO, EPI))) {                      \
+                                       : (W == 16 ? (NT && MT == 1 && rp_fits_fused(G, TT, PRO, EPI))                                            \
+                                                 : (W == 8 && NT && MT == 1 && PRO == 0 && EPI == 1 && TT == 0 && G == 4))) { /* SiLU epilogue in rounds mode */ \
     auto kern = gemv_repacked_kernel<G, TT, W, NT, MT, PRO, EPI>;                                                                       \
     if (lds > 64 * 1024) {                       /* one workgroup per CU: opt in to more of its 160 KiB of LDS, once */                  \
       static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kRpMaxLds);     \

@@ -211,7 +211,7 @@ def test_gemv_repacked_fused_vs_oracle(ops, M):
 
     eps = 1e-5
     for (K, N, g) in [(384, 96, 128), (512, 64, 128), (1024, 1056 * 2, 128), (4096, 12288, 128), (4096, 22016, 128), (2048, 4096, 2048),
-                      (8192, 1024, 128)]:
+                      (8192, 1024, 128), (8192, 10240, 128)]:       # the last: 70B qkv (3-group strips, 4 k-blocks per wave)
         qw, s, qz = synth.make_awq_weights(K, N, g, "f16", "A", seed=M * 31 + K + N)
         h = synth.make_activations(M, K, "f16", "A", seed=M + K + 3)
         delta = synth.make_activations(M, K, "f16", "A", seed=M + K + 4)
@@ -485,10 +485,10 @@ def test_awq_linear_method_apply_matches_oracle(ops):
 
 def test_gemv_repacked_fused_refuses_what_it_cannot_run(ops):
     """Shapes without a fused instantiation return None (AWQ_ERR_BAD_VARIANT at the C boundary) so callers run the
-    separate ops: 16 rows of K = 4096 (prologue registers / LDS), K = 16384 (more than 4 k-blocks per wave)."""
+    separate ops: 16 rows of K = 4096 (prologue chunks per lane), K = 32768 (more than 8 k-blocks per wave)."""
     from sglang_awq_amd import aux_ops
 
-    for (M, K, N) in [(16, 4096, 512), (1, 16384, 256)]:
+    for (M, K, N) in [(16, 4096, 512), (1, 32768, 256)]:
         qw, s, qz = synth.make_awq_weights(K, N, 128, "f16", "A", seed=5)
         packed = ops.awq_repack(*_dev(qw, s, qz))
         h = torch.zeros(M, K, dtype=torch.float16, device=DEV)
@@ -534,3 +534,24 @@ def test_awq_gemm_op_prefill_repacks_on_the_fly(ops):
         assert_gemm_close(to_np(y[:4]), exact, "f16", what=f"awq_gemm op, prefill M={M} K={K} N={N}")
         yb = ops.awq_linear(to_torch(x, DEV), dq, ds, dz, to_torch(b, DEV))
         assert torch.equal(yb, y + to_torch(b, DEV))
+
+
+def test_gemv_repacked_silu_epilogue_rounds_mode(ops):
+    """SiLU-mul epilogue on a matrix too wide for one strip per CU (N > 32768: rounds of 4-group strips), as the 57344-wide
+    gate_up of a 70B model; small K keeps the oracle cheap."""
+    from sglang_awq_amd import aux_ops
+
+    K, N, g = 256, 33280, 128
+    for M in (1, 5):
+        qw, s, qz = synth.make_awq_weights(K, N, g, "f16", "A", seed=M + 90)
+        x = synth.make_activations(M, K, "f16", "A", seed=M + 91)
+        packed_il = ops.awq_repack(*aux_ops.interleave_gate_up(*_dev(qw, s, qz)))
+        r = aux_ops.gemv_repacked_fused(packed_il, K, N, g, x=to_torch(x, DEV), silu_mul=True)
+        assert r is not None
+        _, exact = c_oracle.gemm(x, qw, s, qz, want_exact=True)
+        gu = exact.astype(np.float16)
+        gate, up = gu[:, :N // 2].astype(np.float32), gu[:, N // 2:]
+        want = ((gate / (1.0 + np.exp(-gate))).astype(np.float16) * up).astype(np.float64)
+        got = to_np(r[0]).astype(np.float64)
+        tol = 2.0 * ulp(want, "f16") + 2e-3 * (1.0 + np.abs(exact[:, N // 2:]))
+        assert np.all(np.abs(got - want) <= tol), f"M={M}: worst {np.abs(got - want).max():.3e}"

@@ -91,7 +91,7 @@ def test_aux_argument_validation_without_gpu(lib):
     assert f(h=vp(p), delta=None, w=vp(p), h_out=vp(p + 64), silu=0) == -7        # norm prologue without delta
     assert f(h=vp(p), delta=vp(p), w=vp(p), h_out=vp(p), silu=0) == -7             # h_out aliases h
     assert f(M=16, h=vp(p), delta=vp(p), w=vp(p), h_out=vp(p + 64), silu=0) == -7  # too many rows for the prologue
-    assert f(K=16384, ldx=16384, h=vp(p), delta=vp(p), w=vp(p), h_out=vp(p + 64), silu=0) == -7   # > 4 k-blocks per wave
+    assert f(K=32768, ldx=32768, h=vp(p), delta=vp(p), w=vp(p), h_out=vp(p + 64), silu=0) == -7   # > 8 k-blocks per wave
     att = lambda **kw: lib.awq_aux_decode_attention(kw.get("qkv", vp(p)), vp(p), vp(p), vp(p), vp(p), vp(p), vp(p), 1, 8, kw.get("hkv", 8),
                                                     kw.get("D", 128), 64, 1.0, kw.get("splits", 1), kw.get("ws", None), kw.get("wsb", 0), None)
     assert att(qkv=None) == -1
