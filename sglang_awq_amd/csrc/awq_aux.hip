@@ -24,10 +24,46 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
 }
 
 // h[row] (+= delta[row], written back) ; out[row] = rmsnorm(h[row]) * w.   One workgroup per row, H % 8 == 0.
+// One memory round trip: every thread requests its chunks of h, delta AND w up front and keeps h + delta in registers
+// across the reduction (rows up to 256 x 8 x kNormChunks halves; longer rows take the strided two-pass loop).
+constexpr int kNormChunks = 4;
 __global__ __launch_bounds__(256) void add_rmsnorm_kernel(half_t* __restrict__ h, const half_t* __restrict__ delta,
                                                           const half_t* __restrict__ w, half_t* __restrict__ out, int H, float eps) {
   __shared__ float scratch[8];
   const size_t base = (size_t)blockIdx.x * H;
+  if (H <= 256 * 8 * kNormChunks) {
+    half8v v[kNormChunks], ww[kNormChunks];
+#pragma unroll
+    for (int c = 0; c < kNormChunks; ++c) {
+      const int i = (threadIdx.x + 256 * c) * 8;
+      const int ic = i < H ? i : 0;                       // clamped: loaded, never used
+      v[c] = *(const half8v*)(h + base + ic);
+      if (delta) v[c] = v[c] + *(const half8v*)(delta + base + ic);     // fp16 add, as the eager `h = h + o`
+      ww[c] = *(const half8v*)(w + ic);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < kNormChunks; ++c) {
+      const int i = (threadIdx.x + 256 * c) * 8;
+      if (i < H) {
+        if (delta) *(half8v*)(h + base + i) = v[c];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += (float)v[c][e] * (float)v[c][e];
+      }
+    }
+    const float inv = __builtin_amdgcn_rsqf(block_sum(ss, scratch) / (float)H + eps);
+#pragma unroll
+    for (int c = 0; c < kNormChunks; ++c) {
+      const int i = (threadIdx.x + 256 * c) * 8;
+      if (i < H) {
+        half8v o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)v[c][e] * inv) * ww[c][e];   // round to fp16, then scale (eager order)
+        *(half8v*)(out + base + i) = o;
+      }
+    }
+    return;
+  }
   float ss = 0.f;
   for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) {
     half8v v = *(const half8v*)(h + base + i);
