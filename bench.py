@@ -171,7 +171,8 @@ def main():
 
     def capture(n):
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: the RCCL watchdog thread may touch the runtime while this thread captures (N > 1)
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             for i in range(n):
                 step(i)
         return g

@@ -285,7 +285,7 @@ class GraphedDecoder:
         torch.cuda.current_stream().wait_stream(s)
         graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):     # (the RCCL watchdog thread may touch the runtime meanwhile)
                 self._step()
             self.graph = graph
         except Exception as e:       # e.g. a collective that cannot be captured on this stack: run() then steps eagerly
