@@ -364,33 +364,24 @@ int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
     return rp_fits(w, MT, G, 0) ? 0 : -1;
   };
   int T = depth(W);
-  // 16 waves: stage x through wave-private LDS (5 G registers per k-block instead of 5 G + 16) whenever the batch is
-  // small enough for <= 4 chunks per lane and the LDS — measured faster than fragments in registers on every shape
-  // (4096 x 12288: 8.08 -> 7.74 us, 8192 x 8192: 10.56 -> 9.59) and the only straight-line form that fits for deep
-  // waves (K = 11008, 6 k-blocks per wave: 9.41 -> 7.87 us).  AWQ_RP_XL=0 disables it for A/B runs.
-  int xl = 0;
-  static const int env_xl = rp_env("AWQ_RP_XL", -1);
-  if (W == 16 && !two_tiles && nt && env_t != 0 && env_xl != 0) {
-    const int pw = (KB + 15) / 16;
-    const int per_lane = (a.M * pw * 16 + 63) / 64;
-    const size_t need = (size_t)16 * a.M * 16 * G * sizeof(float) + (size_t)16 * a.M * (pw * 128 + 8) * 2;
-    if (rp_fits_xl(G, pw) && per_lane <= 4 && need <= (size_t)kRpMaxLds) {
-      xl = per_lane <= 1 ? 1 : per_lane <= 2 ? 2 : 4;
-      T = pw;
-    }
+  // 16 waves, M <= 16: the restructured straight-line kernel (gemv_rp2_kernel: x and zs staged through wave-private LDS by the
+  // same few loads, ring of two weight loads per wave, round-robin issue) wherever it has an instantiation; AWQ_RP2=0 /
+  // AWQ_RP2_D=0 (every load up front) are A/B knobs for tools/kbench.
+  // Ring depth: two loads in flight per wave for one row (6.73 -> 6.37 us against every load up front, tools/gemv_lab); with
+  // more rows the x staging loads share the queue and issuing everything up front measured better (M = 4: 7.4 vs 7.7 us).
+  static const int env_rp2 = rp_env("AWQ_RP2", 1), env_d = rp_env("AWQ_RP2_D", -1);
+  if (env_rp2 && W == 16 && !two_tiles && nt && env_t != 0) {
+    const int depth = env_d >= 0 ? env_d : (a.M == 1 ? 2 : 0);
+    if (rp2_launch<0>(G, (KB + 15) / 16, a, packed, NG, depth, nwg)) return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
   }
-  if (!xl && W == 16 && env_waves != 16 && (T < 0 || (T == 0 && (KB + 15) / 16 <= 6))) {   // straight-line did not fit: 8 waves measured better than the 16-wave loop
+  if (W == 16 && env_waves != 16 && (T < 0 || (T == 0 && (KB + 15) / 16 <= 6))) {   // straight-line did not fit: 8 waves measured better than the 16-wave loop
     W = 8;
     T = depth(W);
   }
   if (T < 0) return AWQ_ERR_BAD_VARIANT;
   const int per_wave = (KB + W - 1) / W;
-  size_t lds = (size_t)W * a.M * 16 * G * sizeof(float);
-  if (xl) lds += (size_t)W * a.M * (T * 128 + 8) * 2;
-  if (lds > (size_t)(two_tiles || xl ? kRpMaxLds : 64 * 1024)) return AWQ_ERR_BAD_VARIANT;
-  if (xl == 1) { rp_launch_g<16, true, 1, -1, 0>(G, a, packed, NG, per_wave, T, nwg, lds); return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH; }
-  if (xl == 2) { rp_launch_g<16, true, 1, -2, 0>(G, a, packed, NG, per_wave, T, nwg, lds); return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH; }
-  if (xl == 4) { rp_launch_g<16, true, 1, -4, 0>(G, a, packed, NG, per_wave, T, nwg, lds); return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH; }
+  const size_t lds = (size_t)W * a.M * 16 * G * sizeof(float);
+  if (lds > (size_t)(two_tiles ? kRpMaxLds : 64 * 1024)) return AWQ_ERR_BAD_VARIANT;
   if (two_tiles) rp_launch_g<8, true, 2>(G, a, packed, NG, per_wave, T, nwg, lds);
   else if (W == 16) { if (nt) rp_launch_g<16, true, 1>(G, a, packed, NG, per_wave, T, nwg, lds); else rp_launch_g<16, false, 1>(G, a, packed, NG, per_wave, T, nwg, lds); }
   else { if (nt) rp_launch_g<8, true, 1>(G, a, packed, NG, per_wave, T, nwg, lds); else rp_launch_g<8, false, 1>(G, a, packed, NG, per_wave, T, nwg, lds); }

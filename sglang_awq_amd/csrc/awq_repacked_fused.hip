@@ -59,15 +59,8 @@ int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed) {
     if (!PRO) return AWQ_ERR_BAD_VARIANT;
   }
   size_t lds = (size_t)W * a.M * 16 * G * sizeof(float);
-  if (!norm) {                                                               // SiLU-mul epilogue only: x through wave-private LDS when it fits
-    const int per_lane = (a.M * T * 16 + 63) / 64;
-    const size_t xl_lds = lds + (size_t)W * a.M * (T * 128 + 8) * 2;
-    if (rp_fits_xl(G, T) && per_lane <= 4 && xl_lds <= (size_t)kRpMaxLds) {
-      if (per_lane <= 1) fused_go<-1, 1>(G, a, packed, NG, T, T, nwg, xl_lds);
-      else if (per_lane <= 2) fused_go<-2, 1>(G, a, packed, NG, T, T, nwg, xl_lds);
-      else fused_go<-4, 1>(G, a, packed, NG, T, T, nwg, xl_lds);
-      return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
-    }
+  if (!norm) {                                                               // SiLU-mul epilogue only: the restructured kernel when it has an instantiation
+    if (rp2_launch<1>(G, T, a, packed, NG, a.M == 1 ? 2 : 0, nwg)) return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
   }
   if (!rp_fits_fused(G, T, PRO, a.silu_mul)) return AWQ_ERR_BAD_VARIANT;
   if (norm) lds += (size_t)W * a.M * (T * 128 + 8) * 2 + (size_t)W * PRO * 4 * sizeof(float);

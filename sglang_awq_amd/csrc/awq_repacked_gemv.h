@@ -3,6 +3,8 @@
 // variants of the decode harness (awq_repacked_fused.hip) so the two sets of instantiations build in parallel.
 #pragma once
 
+#include <cstdlib>
+
 #include "awq_device.h"
 #include "awq_kernels.h"
 
@@ -77,8 +79,6 @@ __device__ __forceinline__ void rp_compute(const RpBlock& b, float4_t (&acc)[kRp
 //   PRO = chunks of 8 halves per lane (1, 2 or 4; M * T * 16 <= 64 * PRO): x is not read; every wave builds
 //         x = rmsnorm(h + delta) * w for the columns of its own k-blocks (see the prologue in the kernel);
 //         workgroup 0 also stores h + delta.  Same arithmetic as add_rmsnorm_kernel: fp16 add, fp32 sum of squares, fp16(v * inv) * w.
-//   PRO < 0: no norm, x itself staged compactly through wave-private LDS (-PRO chunks per lane); chosen by the plain
-//         launcher where it lets a straight-line depth fit that would otherwise spill (see the kernel).
 //   EPI = 1: column groups alternate gate / up (repacked from column-interleaved tensors); the epilogue writes
 //         act = fp16(silu(fp16 gate)) * fp16 up, [M, N / 2], instead of y.
 struct RpFuse {
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
                                                                           const void* __restrict__ bias, void* __restrict__ y,
                                                                           int M, int K, int N, int g, int NG, int per_wave,
                                                                           unsigned long long* __restrict__ dbg, RpFuse fz) {
-  static_assert(PRO == 0 || (T > 0 && MT == 1), "x through LDS (norm prologue or not) exists for the straight-line single-tile variants");
+  static_assert(PRO >= 0 && (PRO == 0 || (T > 0 && MT == 1)), "the norm prologue exists for the straight-line single-tile variants");
   extern __shared__ __attribute__((aligned(16))) float red[];    // [W][M][16 G]
 #define RP_STAMP(slot) do { if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   RP_STAMP(0);
@@ -199,35 +199,6 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
           if (blockIdx.x == 0) *(h8_t*)(fz.h_out + (size_t)crow[i] * ldx + col0 + ccol[i]) = hv[i];
         }
       }
-    } else if constexpr (PRO < 0) {
-      // x through wave-private LDS, no norm: the MFMA A layout replicates a row over 16 lanes (16 registers of x per
-      // k-block whatever M is); loaded compactly instead (CH dwordx4 per lane for the wave's own M x T x 128 halves,
-      // requested BEFORE its weights so they return first) and re-read per k-block as fragments, a narrow strip holds
-      // 5 G registers per k-block instead of 5 G + 16 — deep enough straight-line code for K = 11008 at 16 waves.
-      typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
-      constexpr int CH = -PRO, WC = T * 16;
-      const int col0 = kb_begin * 128;
-      h8_t xv[CH];
-      int crow[CH], ccol[CH];
-      bool cok[CH];
-#pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        const int c = lane + i * 64;
-        crow[i] = c / WC;
-        ccol[i] = (c - crow[i] * WC) * 8;
-        cok[i] = crow[i] < M && col0 + ccol[i] < K;
-        xv[i] = *(const h8_t*)((const half_t*)x + (cok[i] ? (size_t)crow[i] * ldx + col0 + ccol[i] : 0));
-      }
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const int kb = kb_begin + t < KB ? kb_begin + t : KB - 1;         // clamped: re-read, then weighted by x = 0
-        rp_load<G, NT, MT, false>(buf[t], qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      RP_STAMP(1);
-#pragma unroll
-      for (int i = 0; i < CH; ++i)
-        if (cok[i]) *(h8_t*)(x_lds + (size_t)crow[i] * XS + ccol[i]) = xv[i];
     } else {
 #pragma unroll
       for (int t = 0; t < T; ++t) {
@@ -318,6 +289,288 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// gemv_rp2_kernel — the straight-line decode GEMV for M <= 16 on 16-wave workgroups (one strip of G column groups per
+// workgroup, T k-blocks per wave), restructured after per-wave stamps and issue-rate measurements (tools/gemv_lab,
+// profiles/r02_gemv_lab_*.txt) showed the previous form (gemv_repacked_kernel with x through LDS) to be bound by vector-ALU
+// issue, not by HBM: a wave's 13 VALU + 1 MFMA per packed dword cost ~70 cycles per dword when it runs alone on its SIMD and
+// ~48 per dword per SIMD with four waves active, against ~27 GB/s per CU of arriving weights; and the CU admits only ~24 KiB
+// of loads in flight, so with every load issued up front the four waves of a SIMD were served, and computed, one after
+// the other.  Changes:
+//   * every vector-memory instruction in the queue is a full 1 KiB weight load: x (M x T x 128 halves) and the wave's
+//     (scale | 1024 + zero) words (G x T x 16 dwords) are fetched by the same CHS <= 8 per-lane-addressed loads and parked
+//     in wave-private LDS (no barrier), instead of 1 + G T separate small loads per wave;
+//   * weight loads go through a ring of D registers sets per wave (D = 2: two 1 KiB loads in flight per wave, 32 KiB per
+//     CU, the next one issued before the current one is dequantised), and the first two issue rounds are separated by
+//     workgroup barriers so the CU's queue holds round k of all sixteen waves before round k + 1 of any: all waves of a
+//     SIMD progress together (4096 x 11008, M = 1: 6.73 -> 6.37 us in the lab harness);
+//   * scale and zero are broadcast into the packed ops through op_sel (no v_perm), masks / magic are opaque compiler-visible
+//     constants (v_and_or_b32 without asm boundary pads), addresses are one wave-uniform base + one per-lane offset:
+//     ~530 instead of ~610 instructions per wave at G = 3, T = 2.
+// Same arithmetic and the same summation order as gemv_repacked_kernel (wave w owns k-blocks [w T, w T + T); partial
+// sums added in wave order through LDS), so results are bit-identical to it.
+// M1: specialisation for one row (M == 1): no row arithmetic in the staging addresses, A fragments broadcast from row 0,
+// one result element per column; CHS is then a function of (G, T) alone.
+template <int G, int T, int CHS, int D, int EPI, bool M1>
+__global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restrict__ x, int64_t ldx, const u32x4_t* __restrict__ qw_r,
+                                                        const uint32_t* __restrict__ zs_r, const void* __restrict__ bias,
+                                                        void* __restrict__ y, int M, int K, int N, int groups, int gmul,
+                                                        int gshift, int NG) {
+  constexpr int W = 16;
+  constexpr int L = G * T;
+  constexpr int DD = (D == 0 || D > L) ? L : D;
+  constexpr int XS = T * 128 + 8;                        // halves per staged x row (+8: rows 16 B apart in bank phase)
+  extern __shared__ __attribute__((aligned(16))) float red[];    // [W][M][16 G] floats, then per wave: x rows, zs words
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, r = lane & 15;
+  const int KB = K / 128;                                // quantisation group of k-block kb: (kb * gmul) >> gshift (= kb / (g / 128), kb < 4096)
+  int cg0 = blockIdx.x * G;
+  if (cg0 + G > NG) cg0 = NG - G;                        // last strip overlaps its neighbour (same values written twice)
+  const int kb0 = wave * T;
+  if constexpr (M1) M = 1;
+  const int xbytes = M * XS * 2;                         // staged x of one wave
+  unsigned char* const stg = (unsigned char*)(red + (size_t)W * M * 16 * G) + (size_t)wave * (xbytes + G * T * 64 + 16);
+
+  // staging chunks (16 B): 16 M T chunks of x (row, 8-half column chunk) and 4 G T chunks of zs words of (c, t).  M == 1:
+  // one id space, lanes take ids lane + 64 i (x first, then zs) -> a single load at G = 3, T = 2.  M > 1: CHS loads of x
+  // chunks, then one load of the (<= 64) zs chunks — no per-lane select between the two address computations.
+  constexpr int NZ = G * T * 4, CHT = M1 ? CHS : CHS + 1;
+  const int nx = M * T * 16;
+  u32x4_t sv[CHT];
+  int sdst[CHT];
+  const int dump = xbytes + G * T * 64;                  // 16-byte slot for lanes without a chunk: the ds_write stays unconditional
+  auto zs_chunk = [&](int j, const unsigned char*& src, int& dst) {       // j in [0, NZ)
+    const int c = j / (T * 4), rem = j - c * (T * 4), t = rem >> 2, part = rem & 3;
+    int kbz = kb0 + t;
+    kbz = kbz < KB ? kbz : KB - 1;
+    src = (const unsigned char*)(zs_r + ((size_t)(cg0 + c) * groups + ((kbz * gmul) >> gshift)) * 16 + part * 4);
+    dst = xbytes + ((c * T + t) * 16 + part * 4) * 4;
+  };
+  if constexpr (M1) {
+#pragma unroll
+    for (int i = 0; i < CHS; ++i) {
+      const int id = lane + 64 * i;
+      const bool isx = id < T * 16;
+      int j = id - T * 16;
+      j = j < 0 ? 0 : (j >= NZ ? NZ - 1 : j);
+      const unsigned char* sz;
+      int dz;
+      zs_chunk(j, sz, dz);
+      const bool xin = isx && (kb0 * 128 + id * 8 < K);
+      const unsigned char* sx = (const unsigned char*)(x + (xin ? (size_t)kb0 * 128 + id * 8 : 0));
+      sv[i] = *(const u32x4_t*)(isx ? sx : sz);
+      if (isx && !xin) sv[i] = (u32x4_t){0u, 0u, 0u, 0u};               // k-blocks past K (ragged last wave): x = 0
+      sdst[i] = id >= T * 16 + NZ ? dump : isx ? id * 16 : dz;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < CHS; ++i) {
+      const int id = lane + 64 * i;
+      const int row = id / (T * 16), cc = id - row * (T * 16);
+      const bool xin = id < nx && (kb0 * 128 + cc * 8 < K);
+      sv[i] = *(const u32x4_t*)(x + (xin ? (size_t)row * ldx + (size_t)kb0 * 128 + cc * 8 : 0));
+      if (!xin) sv[i] = (u32x4_t){0u, 0u, 0u, 0u};                       // k-blocks past K (ragged last wave): x = 0
+      sdst[i] = id < nx ? (row * XS + cc * 8) * 2 : dump;
+    }
+    const unsigned char* sz;
+    int dz;
+    zs_chunk(lane < NZ ? lane : NZ - 1, sz, dz);
+    sv[CHS] = *(const u32x4_t*)sz;
+    sdst[CHS] = lane < NZ ? dz : dump;
+  }
+  // weights: wave-uniform base + lane offset; k-blocks past K are clamped (re-read, weighted by x = 0)
+  const uint32_t loff = (uint32_t)lane * 16u;
+  u32x4_t wbuf[DD];
+  auto load_w = [&](int i) {
+    const int t = i / G, c = i - t * G;
+    int kb = kb0 + t;
+    kb = kb < KB ? kb : KB - 1;
+    const unsigned char* p = (const unsigned char*)(qw_r + ((size_t)(cg0 + c) * KB + kb) * 64) + loff;
+    wbuf[i % DD] = __builtin_nontemporal_load((const u32x4_t*)p);      // streamed once: keep it out of the caches' way
+  };
+#pragma unroll
+  for (int i = 0; i < DD; ++i) {
+    load_w(i);
+    if (D != 0 && i < 2) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < CHT; ++i) *(u32x4_t*)(stg + sdst[i]) = sv[i];
+  __builtin_amdgcn_sched_barrier(0);
+
+  uint32_t mlo = kLoNib, mhi = kHiNib, magic = kMagicF16;
+  asm volatile("" : "+s"(mlo), "+s"(mhi));               // opaque: (w & m) | magic then selects v_and_or_b32 (one literal each)
+  asm volatile("" : "+v"(magic));
+  const half2_t c960 = {(half_t)960.f, (half_t)960.f};
+  const half2_t sixteenth = {(half_t)0.0625f, (half_t)0.0625f};
+  const half_t* x_lds = (const half_t*)stg + (M1 ? 0 : (size_t)(r < M ? r : M - 1) * XS);
+  const uint32_t* zs_lds = (const uint32_t*)(stg + xbytes) + r;
+  float4_t acc[G];
+#pragma unroll
+  for (int c = 0; c < G; ++c) acc[c] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  u32x4_t xa[4];
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    const int t = i / G, c = i - t * G;
+    if (c == 0) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) xa[d] = *(const u32x4_t*)(x_lds + t * 128 + d * 32 + q * 8);
+    }
+    const half2_t zh = as_h2(zs_lds[(c * T + t) * 16]);
+    const half2_t s2 = __builtin_shufflevector(zh, zh, 0, 0);          // folded into op_sel of the packed ops
+    const half2_t z1024 = __builtin_shufflevector(zh, zh, 1, 1);
+    const half2_t z64 = z1024 - c960;                                    // exact: (1024 + z) - 960
+    const u32x4_t w = wbuf[i % DD];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t ww = w[d], w8 = ww >> 8;
+      const half2_t d0 = as_h2((ww & mlo) | magic) - z1024;
+      const half2_t d1 = __builtin_elementwise_fma(as_h2((ww & mhi) | magic), sixteenth, -z64);
+      const half2_t d2 = as_h2((w8 & mlo) | magic) - z1024;
+      const half2_t d3 = __builtin_elementwise_fma(as_h2((w8 & mhi) | magic), sixteenth, -z64);
+      const u32x4_t frag = {as_u32(d0 * s2), as_u32(d1 * s2), as_u32(d2 * s2), as_u32(d3 * s2)};
+      acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, xa[d]), __builtin_bit_cast(half8_t, frag), acc[c], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + DD < L) {
+      load_w(i + DD);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // D[m = 4q + i][n = r] per column group -> LDS, summed over the waves in fixed order
+  const int SW = 16 * G;
+  if constexpr (M1) {
+    if (q == 0) {
+#pragma unroll
+      for (int c = 0; c < G; ++c) red[wave * SW + c * 16 + r] = acc[c][0];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < M) {                                       // wave-uniform
+        const int m = 4 * q + i;
+#pragma unroll
+        for (int c = 0; c < G; ++c)
+          if (m < M) red[((size_t)wave * M + m) * SW + c * 16 + r] = acc[c][i];
+      }
+    }
+  }
+  __syncthreads();
+  if constexpr (EPI == 1) {
+    // strip = G / 2 (gate, up) pairs of column groups; output column = 16 * (pair index) + r of act[M, N / 2]
+    const int SH = 8 * G, I = N / 2;
+    for (int idx = threadIdx.x; idx < M * SH; idx += W * 64) {
+      const int m = M1 ? 0 : idx / SH, c = idx - m * SH;
+      const int pair = c >> 4, r16 = c & 15;
+      const int n = (cg0 / 2 + pair) * 16 + r16;
+      if (n >= I) continue;
+      const int cgate = pair * 32 + r16;
+      float gv = red[(size_t)m * SW + cgate], uv = red[(size_t)m * SW + cgate + 16];
+#pragma unroll
+      for (int w = 1; w < W; ++w) {
+        gv += red[((size_t)w * M + m) * SW + cgate];
+        uv += red[((size_t)w * M + m) * SW + cgate + 16];
+      }
+      const float xg = (float)(half_t)gv;                                // the unfused path rounds gate_up to fp16 first
+      ((half_t*)y)[(size_t)m * I + n] = (half_t)(xg / (1.f + __expf(-xg))) * (half_t)uv;
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < M * SW; idx += W * 64) {
+      const int m = M1 ? 0 : idx / SW, col = idx - m * SW;
+      const int n = cg0 * 16 + col;
+      if (n >= N) continue;
+      float v = red[(size_t)m * SW + col];
+#pragma unroll
+      for (int w = 1; w < W; ++w) v += red[((size_t)w * M + m) * SW + col];
+      store_output<AWQ_DTYPE_F16>(y, (size_t)m * N + n, v, bias, n);
+    }
+  }
+}
+
+// rp2 exists for T <= 8, G <= 8, G T <= 16 (unrolled length), staging of <= 8 chunks per lane; returns false when the
+// (G, T, chunks) combination has no instantiation (caller falls back to gemv_repacked_kernel)
+constexpr bool rp2_fits(int G, int T) { return G >= 1 && G <= kRpMaxG && T >= 1 && T <= 8 && G * T <= 16; }
+inline int rp2_chunks(int M, int G, int T) { (void)G; const int n = (M * T * 16 + 63) / 64; return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : n <= 8 ? 8 : 0; }   // x chunks per lane, M > 1
+inline size_t rp2_lds(int M, int G, int T) { return (size_t)16 * M * 16 * G * sizeof(float) + (size_t)16 * ((size_t)M * (T * 128 + 8) * 2 + (size_t)G * T * 64 + 16); }
+
+template <int G, int T, int EPI>
+static bool rp2_launch_t(const GemmArgs& a, const void* packed, int NG, int chunks, int depth, int nwg, size_t lds) {
+  if constexpr (!rp2_fits(G, T) || (EPI == 1 && (G & 1))) {
+    return false;
+  } else {
+    const u32x4_t* qw_r = (const u32x4_t*)packed;
+    const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
+    const int gk = a.g / 128;                            // k-blocks per quantisation group; kb / gk as a multiply-shift, exact for kb < 4096
+    int lg = 0;
+    while ((1 << lg) < gk) ++lg;
+    const int gshift = 12 + lg, gmul = (int)(((1ll << gshift) + gk - 1) / gk);
+#define RP2_GO(CHS, DEP, ONE)                                                                                                      \
+    do {                                                                                                                           \
+      auto kern = gemv_rp2_kernel<G, T, CHS, DEP, EPI, ONE>;                                                                       \
+      if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kRpMaxLds) != hipSuccess) return false; \
+      hipLaunchKernelGGL(kern, dim3(nwg), dim3(1024), lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r, a.bias, a.y, a.M, a.K, \
+                         a.N, a.K / a.g, gmul, gshift, NG);                                                                        \
+      return true;                                                                                                                 \
+    } while (0)
+    static const bool env_m1 = !(getenv("AWQ_RP2_M1") && atoi(getenv("AWQ_RP2_M1")) == 0);   // A/B knob
+    if (a.M == 1 && env_m1) {
+      constexpr int C1 = (T * 16 + G * T * 4 + 63) / 64;          // <= 5 for G T <= 16
+      constexpr int CH1 = C1 <= 1 ? 1 : C1 <= 2 ? 2 : C1 <= 4 ? 4 : 8;
+      if (depth == 0) RP2_GO(CH1, 0, true);
+      RP2_GO(CH1, 2, true);
+    }
+    if (depth == 0) {
+      if (chunks == 1) RP2_GO(1, 0, false);
+      if (chunks == 2) RP2_GO(2, 0, false);
+      if (chunks == 4) RP2_GO(4, 0, false);
+      if (chunks == 8) RP2_GO(8, 0, false);
+    } else {
+      if (chunks == 1) RP2_GO(1, 2, false);
+      if (chunks == 2) RP2_GO(2, 2, false);
+      if (chunks == 4) RP2_GO(4, 2, false);
+      if (chunks == 8) RP2_GO(8, 2, false);
+    }
+#undef RP2_GO
+    return false;
+  }
+}
+
+template <int G, int EPI>
+static bool rp2_launch_g(int T, const GemmArgs& a, const void* packed, int NG, int chunks, int depth, int nwg, size_t lds) {
+  switch (T) {
+    case 1: return rp2_launch_t<G, 1, EPI>(a, packed, NG, chunks, depth, nwg, lds);
+    case 2: return rp2_launch_t<G, 2, EPI>(a, packed, NG, chunks, depth, nwg, lds);
+    case 3: return rp2_launch_t<G, 3, EPI>(a, packed, NG, chunks, depth, nwg, lds);
+    case 4: return rp2_launch_t<G, 4, EPI>(a, packed, NG, chunks, depth, nwg, lds);
+    case 5: return rp2_launch_t<G, 5, EPI>(a, packed, NG, chunks, depth, nwg, lds);
+    case 6: return rp2_launch_t<G, 6, EPI>(a, packed, NG, chunks, depth, nwg, lds);
+    case 7: return rp2_launch_t<G, 7, EPI>(a, packed, NG, chunks, depth, nwg, lds);
+    case 8: return rp2_launch_t<G, 8, EPI>(a, packed, NG, chunks, depth, nwg, lds);
+    default: return false;
+  }
+}
+
+// launches gemv_rp2_kernel if an instantiation exists for (G, T = per-wave k-blocks at 16 waves, M); false = nothing enqueued
+template <int EPI>
+static bool rp2_launch(int G, int T, const GemmArgs& a, const void* packed, int NG, int depth, int nwg) {
+  const int chunks = rp2_chunks(a.M, G, T);
+  const size_t lds = rp2_lds(a.M, G, T);
+  if (!chunks || a.M > 16 || lds > (size_t)kRpMaxLds || a.K / 128 >= 4096 || a.g / 128 >= 4096) return false;
+  switch (G) {
+    case 1: return rp2_launch_g<1, EPI>(T, a, packed, NG, chunks, depth, nwg, lds);
+    case 2: return rp2_launch_g<2, EPI>(T, a, packed, NG, chunks, depth, nwg, lds);
+    case 3: return rp2_launch_g<3, EPI>(T, a, packed, NG, chunks, depth, nwg, lds);
+    case 4: return rp2_launch_g<4, EPI>(T, a, packed, NG, chunks, depth, nwg, lds);
+    case 5: return rp2_launch_g<5, EPI>(T, a, packed, NG, chunks, depth, nwg, lds);
+    case 6: return rp2_launch_g<6, EPI>(T, a, packed, NG, chunks, depth, nwg, lds);
+    case 7: return rp2_launch_g<7, EPI>(T, a, packed, NG, chunks, depth, nwg, lds);
+    case 8: return rp2_launch_g<8, EPI>(T, a, packed, NG, chunks, depth, nwg, lds);
+    default: return false;
+  }
+}
+
 // Which (waves, row tiles, strip width G, straight-line depth T) instantiations fit their register budget
 // (128 VGPRs at 16 waves, 256 at 8) without scratch — from hipcc's -Rpass-analysis=kernel-resource-usage
 // (tools/rp_resources.py prints the table).  A spilling variant is never built nor chosen: G = 3, T = 4 at
@@ -350,7 +603,6 @@ static void rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wav
   dim3 grid(nwg), block(W * 64);
 #define RP_GO(TT)                                                                                                                     \
   if constexpr ((PRO == 0 && EPI == 0) ? (TT <= 6 && rp_fits(W, MT, G, TT) && (MT == 1 || TT == 0 || TT == 4))                           \
-                : (PRO < 0)            ? (W == 16 && NT && MT == 1 && !(EPI && (G & 1)) && rp_fits_xl(G, TT))                            \
                 : (MT == 2)            ? (PRO == 0 && W == 8 && NT && !(G & 1) && rp_fits(8, 2, G, TT))   /* SiLU-mul epilogue, 17..32 rows */ \
                                        : (W == 16 ? (NT && MT == 1 && rp_fits_fused(G, TT, PRO, EPI))                                            \
                                                  : (W == 8 && NT && MT == 1 && PRO == 0 && EPI == 1 && TT == 0 && G == 4))) { /* SiLU epilogue in rounds mode */ \

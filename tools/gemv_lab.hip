@@ -1,0 +1,815 @@
+// gemv_lab — experimental bench for the decode GEMV on the repacked (MFMA-fragment-major) layout.
+//
+// Diagnostic tool, not product code: candidate structures of the M <= 16 GEMV with ablation switches and per-wave
+// time stamps, checked against libawq_hip.so's awq_gemm_repacked on the same packed weights.  What was learned here
+// is recorded in DESIGN.md; the winning structure lives in sglang_awq_amd/csrc/awq_repacked_gemv.h.
+//
+//   tools/gemv_lab time   K N [sets=16] [iters=400] [filter]     time every variant whose name contains `filter`
+//   tools/gemv_lab stamps K N variant [sets=16]                  per-wave stamps of one variant
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../include/awq_hip.h"
+#include "../sglang_awq_amd/csrc/awq_device.h"
+
+using namespace awq;
+
+#define CK(x)                                                                                  \
+  do {                                                                                         \
+    hipError_t e_ = (x);                                                                       \
+    if (e_ != hipSuccess) {                                                                    \
+      fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__);   \
+      exit(1);                                                                                 \
+    }                                                                                          \
+  } while (0)
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static inline uint64_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
+static void fill_u32(void* dptr, size_t n_words) {
+  std::vector<uint32_t> h(n_words);
+  for (size_t i = 0; i < n_words; ++i) h[i] = (uint32_t)(rnd() >> 16);
+  CK(hipMemcpy(dptr, h.data(), n_words * 4, hipMemcpyHostToDevice));
+}
+static void fill_half(void* dptr, size_t n, float lo, float hi) {
+  std::vector<uint16_t> h(n);
+  for (size_t i = 0; i < n; ++i) {
+    _Float16 v = (_Float16)(lo + (hi - lo) * (float)((rnd() >> 40) * (1.0 / (1 << 24))));
+    memcpy(&h[i], &v, 2);
+  }
+  CK(hipMemcpy(dptr, h.data(), n * 2, hipMemcpyHostToDevice));
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32x4_t lab_dequant(uint32_t w, half2_t z1024, half2_t z64, half2_t s2) {
+  const half2_t sixteenth = {(half_t)0.0625f, (half_t)0.0625f};
+  const uint32_t magic = kMagicF16;
+  const uint32_t w8 = w >> 8;
+  const half2_t d0 = as_h2(and_or(w, kLoNib, magic)) - z1024;
+  const half2_t d1 = __builtin_elementwise_fma(as_h2(and_or(w, kHiNib, magic)), sixteenth, -z64);
+  const half2_t d2 = as_h2(and_or(w8, kLoNib, magic)) - z1024;
+  const half2_t d3 = __builtin_elementwise_fma(as_h2(and_or(w8, kHiNib, magic)), sixteenth, -z64);
+  return (u32x4_t){as_u32(d0 * s2), as_u32(d1 * s2), as_u32(d2 * s2), as_u32(d3 * s2)};
+}
+
+struct LabArgs {
+  const uint16_t* x;
+  const u32x4_t* qw_r;
+  const uint32_t* zs_r;
+  uint16_t* y;
+  int M, K, N, NG, KB;
+  unsigned long long* dbg;    // [nwg][W][8] stamps, or null
+};
+
+// G column groups per workgroup, T k-blocks per wave (W * T == KB), D = weight loads kept in flight per wave (0 = all),
+// ZF: zs loads issued first, ABL: 0 full, 1 no dequantise (raw dword as fragment), 2 no VALU / MFMA (xor), 3 no reduction,
+// BAR: workgroup barrier between the first issue rounds (interleaves the waves' requests), MAPI: wave w takes k-blocks
+// w, w + W, ... instead of a contiguous range, NT: non-temporal weight loads.
+template <int G, int T, int W, int D, int ZF, int ABL, int BAR, int MAPI, int NT>
+__global__ __launch_bounds__(W * 64) void lab_kernel(LabArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float red[];    // [W][16 G] floats (row 0 only; the lab runs M = 1), then x slices
+  constexpr int L = G * T;
+  constexpr int DD = (D == 0 || D > L) ? L : D;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, r = lane & 15;
+  unsigned long long* dbg = a.dbg ? a.dbg + ((size_t)blockIdx.x * W + wave) * 8 : nullptr;
+#define STAMP(slot) do { if (dbg && lane == 0) dbg[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  STAMP(0);
+  int cg0 = blockIdx.x * G;
+  if (cg0 + G > a.NG) cg0 = a.NG - G;
+  const int KB = a.KB;
+  int kbs[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) kbs[t] = MAPI ? wave + t * W : wave * T + t;
+
+  // x: this wave's T x 128 halves (row 0), compactly: lanes 0 .. T*16-1 load 16 B each
+  half_t* const x_lds = (half_t*)(red + (size_t)W * 16 * G) + (size_t)wave * (T * 128 + 8);
+  u32x4_t xv = {0u, 0u, 0u, 0u};
+  const bool xok = lane < T * 16;
+  {
+    const int t = lane >> 4, ch = lane & 15;
+    const int kb = xok ? (MAPI ? wave + t * W : wave * T + t) : 0;
+    xv = *(const u32x4_t*)(a.x + (size_t)kb * 128 + ch * 8);
+  }
+  uint32_t zs[T][G];
+  u32x4_t wbuf[DD];
+  auto load_zs = [&](int t) {
+#pragma unroll
+    for (int c = 0; c < G; ++c) zs[t][c] = a.zs_r[((size_t)(cg0 + c) * KB + kbs[t]) * 16 + r];   // g = 128: one group per k-block
+  };
+  auto load_w = [&](int i) {
+    const int t = i / G, c = i % G;
+    const u32x4_t* p = a.qw_r + ((size_t)(cg0 + c) * KB + kbs[t]) * 64 + lane;
+    wbuf[i % DD] = NT ? __builtin_nontemporal_load(p) : *p;
+  };
+  if constexpr (ZF) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) load_zs(t);
+  }
+#pragma unroll
+  for (int i = 0; i < DD; ++i) {
+    load_w(i);
+    if constexpr (!ZF) { if ((i % G) == G - 1) load_zs(i / G); }
+    if constexpr (BAR) { if (i < BAR) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  STAMP(1);
+  if (xok) *(u32x4_t*)(x_lds + (lane >> 4) * 128 + (lane & 15) * 8) = xv;
+  __builtin_amdgcn_sched_barrier(0);
+
+  float4_t acc[G];
+#pragma unroll
+  for (int c = 0; c < G; ++c) acc[c] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  const half2_t c960 = {(half_t)960.f, (half_t)960.f};
+  u32x4_t xa[4];
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    const int t = i / G, c = i % G;
+    if (c == 0) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) xa[d] = *(const u32x4_t*)(x_lds + t * 128 + d * 32 + q * 8);
+    }
+    const u32x4_t w = wbuf[i % DD];
+    if constexpr (ABL == 2) {
+      acc[c][0] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, acc[c][0]) ^ w[0] ^ w[1] ^ w[2] ^ w[3] ^ zs[t][c] ^ xa[0][0]);
+    } else {
+      const half2_t s2 = as_h2(pack_lo16(zs[t][c], zs[t][c]));
+      const half2_t z1024 = as_h2(pack_hi16(zs[t][c], zs[t][c]));
+      const half2_t z64 = z1024 - c960;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        u32x4_t frag;
+        if constexpr (ABL == 1) frag = (u32x4_t){w[d], w[d] ^ zs[t][c], w[d], w[d]};
+        else frag = lab_dequant(w[d], z1024, z64, s2);
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, xa[d]), __builtin_bit_cast(half8_t, frag), acc[c], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + DD < L) {
+      load_w(i + DD);
+      if constexpr (!ZF) { if (((i + DD) % G) == G - 1) load_zs((i + DD) / G); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (i == 0) STAMP(2);
+    if (i == L / 2) STAMP(3);
+  }
+  STAMP(4);
+  if constexpr (ABL == 3) {
+    if (wave == 0 && q == 0) {
+#pragma unroll
+      for (int c = 0; c < G; ++c) {
+        const int n = (cg0 + c) * 16 + r;
+        if (n < a.N) a.y[n] = float_to_half_bits(acc[c][0]);
+      }
+    }
+    return;
+  }
+  // row 0 lives in lanes q == 0, element 0
+  if (q == 0) {
+#pragma unroll
+    for (int c = 0; c < G; ++c) red[wave * (16 * G) + c * 16 + r] = acc[c][0];
+  }
+  __syncthreads();
+  STAMP(5);
+  if (threadIdx.x < 16 * G) {
+    const int col = threadIdx.x;
+    float v = red[col];
+#pragma unroll
+    for (int w = 1; w < W; ++w) v += red[w * (16 * G) + col];
+    const int n = cg0 * 16 + col;
+    if (n < a.N) a.y[n] = float_to_half_bits(v);
+  }
+  STAMP(6);
+#undef STAMP
+}
+
+
+// Second structure: x and zs of a wave are fetched by ONE load instruction (per-lane addresses: lanes 0 .. 16 T - 1 take
+// the x chunks, the next 4 G T lanes the zs chunks) and staged through wave-private LDS, so that (nearly) every
+// vector-memory instruction in the CU's queue is a full 1 KiB weight load; D = weight loads in flight per wave.
+template <int G, int T, int W, int D, int ABL, int NT, int PRIO>
+__global__ __launch_bounds__(W * 64) void lab2_kernel(LabArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  constexpr int L = G * T;
+  constexpr int DD = (D == 0 || D > L) ? L : D;
+  constexpr int XS = T * 128 + 8;                 // halves
+  constexpr int STG = XS * 2 + G * T * 64;        // bytes of staging per wave
+  static_assert(T * 16 + G * T * 4 <= 64, "one staging instruction");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, r = lane & 15;
+  unsigned long long* dbg = a.dbg ? a.dbg + ((size_t)blockIdx.x * W + wave) * 8 : nullptr;
+#define STAMP(slot) do { if (dbg && lane == 0) dbg[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  STAMP(0);
+  int cg0 = blockIdx.x * G;
+  if (cg0 + G > a.NG) cg0 = a.NG - G;
+  const int KB = a.KB;
+  const int kb0 = wave * T;
+  unsigned char* const stg = (unsigned char*)(red + (size_t)W * 16 * G) + (size_t)wave * STG;
+  // staging load
+  const unsigned char* src;
+  int dst;
+  {
+    const int j = lane - T * 16;
+    const int jc = j < 0 ? 0 : (j >= G * T * 4 ? G * T * 4 - 1 : j);
+    const int c = jc / (T * 4), jj = jc % (T * 4);
+    const unsigned char* sx = (const unsigned char*)(a.x + (size_t)kb0 * 128) + lane * 16;
+    const unsigned char* sz = (const unsigned char*)(a.zs_r + ((size_t)(cg0 + c) * KB + kb0) * 16) + jj * 16;
+    src = j < 0 ? sx : sz;
+    dst = j < 0 ? lane * 16 : XS * 2 + (c * T * 4 + jj) * 16;
+  }
+  const u32x4_t sv = *(const u32x4_t*)src;
+  u32x4_t wbuf[DD];
+  auto load_w = [&](int i) {
+    const int t = i / G, c = i % G;
+    const u32x4_t* p = a.qw_r + ((size_t)(cg0 + c) * KB + kb0 + t) * 64 + lane;
+    wbuf[i % DD] = NT ? __builtin_nontemporal_load(p) : *p;
+  };
+#pragma unroll
+  for (int i = 0; i < DD; ++i) load_w(i);
+  __builtin_amdgcn_sched_barrier(0);
+  STAMP(1);
+  if (lane < T * 16 + G * T * 4) *(u32x4_t*)(stg + dst) = sv;
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (PRIO) __builtin_amdgcn_s_setprio(PRIO);
+
+  float4_t acc[G];
+#pragma unroll
+  for (int c = 0; c < G; ++c) acc[c] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  const half2_t c960 = {(half_t)960.f, (half_t)960.f};
+  const half_t* x_lds = (const half_t*)stg;
+  const uint32_t* zs_lds = (const uint32_t*)(stg + XS * 2);
+  u32x4_t xa[4];
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    const int t = i / G, c = i % G;
+    if (c == 0) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) xa[d] = *(const u32x4_t*)(x_lds + t * 128 + d * 32 + q * 8);
+    }
+    const uint32_t zsv = zs_lds[(c * T + t) * 16 + r];
+    const u32x4_t w = wbuf[i % DD];
+    if constexpr (ABL == 2) {
+      acc[c][0] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, acc[c][0]) ^ w[0] ^ w[1] ^ w[2] ^ w[3] ^ zsv ^ xa[0][0]);
+    } else {
+      const half2_t s2 = as_h2(pack_lo16(zsv, zsv));
+      const half2_t z1024 = as_h2(pack_hi16(zsv, zsv));
+      const half2_t z64 = z1024 - c960;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const u32x4_t frag = lab_dequant(w[d], z1024, z64, s2);
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, xa[d]), __builtin_bit_cast(half8_t, frag), acc[c], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + DD < L) {
+      load_w(i + DD);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (i == 0) STAMP(2);
+    if (i == L / 2) STAMP(3);
+  }
+  STAMP(4);
+  if (q == 0) {
+#pragma unroll
+    for (int c = 0; c < G; ++c) red[wave * (16 * G) + c * 16 + r] = acc[c][0];
+  }
+  __syncthreads();
+  STAMP(5);
+  if (threadIdx.x < 16 * G) {
+    const int col = threadIdx.x;
+    float v = red[col];
+#pragma unroll
+    for (int w = 1; w < W; ++w) v += red[w * (16 * G) + col];
+    const int n = cg0 * 16 + col;
+    if (n < a.N) a.y[n] = float_to_half_bits(v);
+  }
+  STAMP(6);
+#undef STAMP
+}
+
+
+// Third structure: lab2 with the instruction count trimmed — weight addresses as a wave-uniform base + one per-lane
+// 32-bit offset, (a & mask) | magic from compiler-visible opaque constants (no asm boundary pads), scale / zero
+// broadcast through op_sel instead of v_perm, stamps compiled out unless STAMPS.
+//   ABL: 0 full, 2 read-only (xor), 4 read-only without the reduction (no LDS write, no barrier), 5 read-only without any
+//   staging (weights only), 6 full compute without x / zs staging (constant x, zs)  -- timing ablations
+template <int G, int T, int W, int D, int ABL, int NT, int SB>
+__global__ __launch_bounds__(W * 64) void lab3_kernel(LabArgs a) {
+  constexpr int STAMPS = SB & 1, BAR = SB >> 1;     // SB = stamps + 2 * (initial issue rounds separated by workgroup barriers)
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  constexpr int L = G * T;
+  constexpr int DD = (D == 0 || D > L) ? L : D;
+  constexpr int XS = T * 128 + 8;                 // halves
+  constexpr int STG = XS * 2 + G * T * 64;        // bytes of staging per wave
+  constexpr int NCH = T * 16 + G * T * 4;         // staging chunks (16 B) of this wave: x, then zs
+  constexpr int CH = (NCH + 63) / 64;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, r = lane & 15;
+  unsigned long long* dbg = (STAMPS && a.dbg) ? a.dbg + ((size_t)blockIdx.x * W + wave) * 8 : nullptr;
+#define STAMP(slot) do { if constexpr (STAMPS) { if (dbg && lane == 0) dbg[slot] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+  STAMP(0);
+  int cg0 = blockIdx.x * G;
+  if (cg0 + G > a.NG) cg0 = a.NG - G;
+  const int KB = a.KB;
+  const int kb0 = wave * T;
+  unsigned char* const stg = (unsigned char*)(red + (size_t)W * 16 * G) + (size_t)wave * STG;
+  // staging loads: chunk ids 0 .. 16 T - 1 are x chunks, the next 4 G T are zs chunks; lane takes ids lane + 64 i
+  u32x4_t sv[CH];
+  int dst[CH];
+  if constexpr (ABL != 5 && ABL != 6) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int id = lane + 64 * i;
+      const int j = id - T * 16;
+      const int jc = j < 0 ? 0 : (j >= G * T * 4 ? G * T * 4 - 1 : j);
+      const int c = jc / (T * 4), jj = jc % (T * 4);
+      const unsigned char* sx = (const unsigned char*)(a.x + (size_t)kb0 * 128) + (id < T * 16 ? id : 0) * 16;
+      const unsigned char* sz = (const unsigned char*)(a.zs_r + ((size_t)(cg0 + c) * KB + kb0) * 16) + jj * 16;
+      sv[i] = *(const u32x4_t*)(j < 0 ? sx : sz);
+      dst[i] = j < 0 ? id * 16 : XS * 2 + (c * T * 4 + jj) * 16;
+    }
+  }
+  const unsigned char* wbase = (const unsigned char*)(a.qw_r + ((size_t)cg0 * KB + kb0) * 64);     // wave-uniform
+  const uint32_t loff = (uint32_t)lane * 16u;
+  u32x4_t wbuf[DD];
+  auto load_w = [&](int i) {
+    const int t = i / G, c = i % G;
+    const u32x4_t* p = (const u32x4_t*)(wbase + ((size_t)c * KB + t) * 1024 + loff);
+    wbuf[i % DD] = NT ? __builtin_nontemporal_load(p) : *p;
+  };
+#pragma unroll
+  for (int i = 0; i < DD; ++i) {
+    load_w(i);
+    if (i < BAR) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  STAMP(1);
+  if constexpr (ABL != 5 && ABL != 6) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+      if (lane + 64 * i < NCH) *(u32x4_t*)(stg + dst[i]) = sv[i];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  uint32_t mlo = kLoNib, mhi = kHiNib, magic = kMagicF16;
+  asm volatile("" : "+s"(mlo), "+s"(mhi));
+  asm volatile("" : "+v"(magic));
+  float4_t acc[G];
+#pragma unroll
+  for (int c = 0; c < G; ++c) acc[c] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  const half2_t c960 = {(half_t)960.f, (half_t)960.f};
+  const half2_t sixteenth = {(half_t)0.0625f, (half_t)0.0625f};
+  const half_t* x_lds = (const half_t*)stg;
+  const uint32_t* zs_lds = (const uint32_t*)(stg + XS * 2);
+  u32x4_t xa[4];
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    const int t = i / G, c = i % G;
+    if (c == 0) {
+      if constexpr (ABL == 5 || ABL == 6) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) xa[d] = (u32x4_t){0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+      } else {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) xa[d] = *(const u32x4_t*)(x_lds + t * 128 + d * 32 + q * 8);
+      }
+    }
+    uint32_t zsv;
+    if constexpr (ABL == 5 || ABL == 6) zsv = 0x64082000u + lane; else zsv = zs_lds[(c * T + t) * 16 + r];
+    const u32x4_t w = wbuf[i % DD];
+    if constexpr (ABL == 2 || ABL == 4 || ABL == 5) {
+      acc[c][0] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, acc[c][0]) ^ w[0] ^ w[1] ^ w[2] ^ w[3] ^ zsv ^ xa[0][0]);
+    } else {
+      const half2_t zh = as_h2(zsv);
+      const half2_t s2 = __builtin_shufflevector(zh, zh, 0, 0);
+      const half2_t z1024 = __builtin_shufflevector(zh, zh, 1, 1);
+      const half2_t z64 = z1024 - c960;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const uint32_t ww = w[d], w8 = ww >> 8;
+        const half2_t d0 = as_h2((ww & mlo) | magic) - z1024;
+        const half2_t d1 = __builtin_elementwise_fma(as_h2((ww & mhi) | magic), sixteenth, -z64);
+        const half2_t d2 = as_h2((w8 & mlo) | magic) - z1024;
+        const half2_t d3 = __builtin_elementwise_fma(as_h2((w8 & mhi) | magic), sixteenth, -z64);
+        const u32x4_t frag = {as_u32(d0 * s2), as_u32(d1 * s2), as_u32(d2 * s2), as_u32(d3 * s2)};
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, xa[d]), __builtin_bit_cast(half8_t, frag), acc[c], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + DD < L) {
+      load_w(i + DD);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (i == 0) STAMP(2);
+    if (i == L / 2) STAMP(3);
+  }
+  STAMP(4);
+  if constexpr (ABL == 4 || ABL == 5) {
+    if (q == 0) {
+      uint32_t v = 0;
+#pragma unroll
+      for (int c = 0; c < G; ++c) v ^= __builtin_bit_cast(uint32_t, acc[c][0]);
+      if (v == 0x12345678u) a.y[lane] = 1;
+    }
+    return;
+  }
+  if (q == 0) {
+#pragma unroll
+    for (int c = 0; c < G; ++c) red[wave * (16 * G) + c * 16 + r] = acc[c][0];
+  }
+  __syncthreads();
+  STAMP(5);
+  if (threadIdx.x < 16 * G) {
+    const int col = threadIdx.x;
+    float v = red[col];
+#pragma unroll
+    for (int w = 1; w < W; ++w) v += red[w * (16 * G) + col];
+    const int n = cg0 * 16 + col;
+    if (n < a.N) a.y[n] = float_to_half_bits(v);
+  }
+  STAMP(6);
+#undef STAMP
+}
+
+struct Variant {
+  const char* name;
+  int G, W;
+  void (*launch)(const LabArgs&, int nwg, size_t lds, hipStream_t st);
+  bool exact_compute;      // ABL == 0 or 3-with-W... (checked against the library only when true)
+};
+
+template <int G, int T, int W, int D, int ZF, int ABL, int BAR, int MAPI, int NT>
+static void launch_v(const LabArgs& a, int nwg, size_t lds, hipStream_t st) {
+  auto kern = lab_kernel<G, T, W, D, ZF, ABL, BAR, MAPI, NT>;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(W * 64), lds, st, a);
+}
+
+template <int G, int T, int W, int D, int ABL, int NT, int PRIO>
+static void launch_v2(const LabArgs& a, int nwg, size_t lds, hipStream_t st) {
+  auto kern = lab2_kernel<G, T, W, D, ABL, NT, PRIO>;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(W * 64), lds, st, a);
+}
+#define V2(G, T, W, D, ABL, NT, PRIO) {"v2g" #G "t" #T "w" #W "d" #D "a" #ABL "n" #NT "p" #PRIO, G, W, launch_v2<G, T, W, D, ABL, NT, PRIO>, ABL == 0}
+
+template <int G, int T, int W, int D, int ABL, int NT, int STAMPS>
+static void launch_v3_unused();
+template <int G, int T, int W, int D, int ABL, int NT, int STAMPS>
+static void launch_v3(const LabArgs& a, int nwg, size_t lds, hipStream_t st) {
+  auto kern = lab3_kernel<G, T, W, D, ABL, NT, STAMPS>;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(W * 64), lds, st, a);
+}
+#define V3(G, T, W, D, ABL, NT, STAMPS) {"v3g" #G "t" #T "w" #W "d" #D "a" #ABL "n" #NT "s" #STAMPS, G, W, launch_v3<G, T, W, D, ABL, NT, STAMPS>, ABL == 0}
+
+// name encodes: g<G>t<T>w<W>d<D>z<ZF>a<ABL>b<BAR>m<MAPI>n<NT>
+#define V(G, T, W, D, ZF, ABL, BAR, MAPI, NT) \
+  {"g" #G "t" #T "w" #W "d" #D "z" #ZF "a" #ABL "b" #BAR "m" #MAPI "n" #NT, G, W, launch_v<G, T, W, D, ZF, ABL, BAR, MAPI, NT>, ABL == 0}
+
+// K = 4096 (KB = 32) variants: W * T == 32
+static const Variant kVariants4096[] = {
+    // the product's structure (16 waves, T = 2, all loads up front, zs after each block's weights), and its ablations
+    V(3, 2, 16, 0, 0, 0, 0, 0, 1),
+    V(3, 2, 16, 0, 0, 1, 0, 0, 1),
+    V(3, 2, 16, 0, 0, 2, 0, 0, 1),
+    V(3, 2, 16, 0, 0, 3, 0, 0, 1),
+    // zs first
+    V(3, 2, 16, 0, 1, 0, 0, 0, 1),
+    V(3, 2, 16, 0, 1, 2, 0, 0, 1),
+    // interleaved k-block map
+    V(3, 2, 16, 0, 1, 0, 0, 1, 1),
+    // limited depth
+    V(3, 2, 16, 3, 1, 0, 0, 0, 1),
+    V(3, 2, 16, 4, 1, 0, 0, 0, 1),
+    V(3, 2, 16, 2, 1, 0, 0, 0, 1),
+    // barrier-interleaved issue
+    V(3, 2, 16, 0, 1, 0, 3, 0, 1),
+    V(3, 2, 16, 0, 1, 0, 6, 0, 1),
+    V(3, 2, 16, 0, 1, 0, 3, 1, 1),
+    // default-policy loads
+    V(3, 2, 16, 0, 1, 0, 0, 0, 0),
+    // 8 waves, T = 4
+    V(3, 4, 8, 0, 1, 0, 0, 0, 1),
+    V(3, 4, 8, 6, 1, 0, 0, 0, 1),
+    V(3, 4, 8, 4, 1, 0, 0, 0, 1),
+    V(3, 4, 8, 0, 1, 2, 0, 0, 1),
+    // 4 waves, T = 8 (one wave per SIMD)
+    V(3, 8, 4, 12, 1, 0, 0, 0, 1),
+    V(3, 8, 4, 8, 1, 0, 0, 0, 1),
+    V(3, 8, 4, 0, 1, 2, 0, 0, 1),
+    // narrower strips, more workgroups (two or more resident per CU)
+    V(1, 4, 8, 0, 1, 0, 0, 0, 1),
+    V(1, 4, 8, 0, 1, 2, 0, 0, 1),
+    V(2, 4, 8, 0, 1, 0, 0, 0, 1),
+    V(1, 8, 4, 0, 1, 0, 0, 0, 1),
+    V(1, 8, 4, 0, 1, 2, 0, 0, 1),
+    V(2, 8, 4, 0, 1, 0, 0, 0, 1),
+    V(1, 2, 16, 0, 1, 0, 0, 0, 1),
+    V3(3, 2, 16, 0, 0, 1, 0),
+    V3(3, 2, 16, 2, 0, 1, 4),
+    V3(3, 2, 16, 3, 0, 1, 6),
+    V3(3, 2, 16, 3, 0, 1, 2),
+    V3(3, 2, 16, 0, 0, 1, 12),
+    V3(3, 2, 16, 0, 0, 1, 4),
+    V3(3, 2, 16, 2, 0, 1, 5),
+    V3(3, 2, 16, 3, 0, 1, 7),
+    V3(3, 4, 8, 3, 0, 1, 6),
+    V3(3, 4, 8, 4, 0, 1, 8),
+    V3(3, 4, 8, 6, 0, 1, 12),
+    V3(3, 4, 8, 6, 0, 1, 6),
+    V3(3, 8, 4, 6, 0, 1, 0),
+    V3(3, 8, 4, 8, 0, 1, 0),
+    V3(3, 8, 4, 12, 0, 1, 0),
+    V3(3, 8, 4, 6, 0, 1, 1),
+    V3(3, 8, 4, 6, 2, 1, 0),
+    V3(3, 8, 4, 6, 4, 1, 0),
+    V3(3, 4, 8, 3, 0, 1, 0),
+    V3(3, 4, 8, 4, 0, 1, 0),
+    V3(3, 4, 8, 6, 0, 1, 0),
+    V3(3, 4, 8, 3, 0, 1, 1),
+    V3(3, 4, 8, 4, 2, 1, 0),
+    V3(3, 2, 16, 0, 0, 1, 1),
+    V3(3, 2, 16, 3, 0, 1, 0),
+    V3(3, 2, 16, 2, 0, 1, 0),
+    V3(3, 2, 16, 0, 2, 1, 0),
+    V3(3, 2, 16, 0, 4, 1, 0),
+    V3(3, 2, 16, 0, 5, 1, 0),
+    V3(3, 2, 16, 0, 6, 1, 0),
+    V3(3, 2, 16, 0, 2, 1, 1),
+    V3(3, 2, 16, 0, 4, 1, 1),
+    V3(2, 2, 16, 0, 0, 1, 0),
+    V3(1, 2, 16, 0, 0, 1, 0),
+    V3(1, 2, 16, 0, 4, 1, 0),
+    V3(1, 2, 16, 0, 5, 1, 0),
+    V2(3, 2, 16, 0, 0, 1, 0),
+    V2(3, 2, 16, 0, 2, 1, 0),
+    V2(3, 2, 16, 5, 0, 1, 0),
+    V2(3, 2, 16, 4, 0, 1, 0),
+    V2(3, 2, 16, 3, 0, 1, 0),
+    V2(3, 2, 16, 2, 0, 1, 0),
+    V2(3, 2, 16, 1, 0, 1, 0),
+    V2(3, 2, 16, 3, 2, 1, 0),
+    V2(3, 2, 16, 4, 0, 1, 1),
+    V2(3, 2, 16, 0, 0, 0, 0),
+    V2(3, 2, 16, 4, 0, 0, 0),
+    V2(1, 2, 16, 0, 0, 1, 0),
+    V2(2, 2, 16, 0, 0, 1, 0),
+};
+
+static std::vector<uint16_t> d2h_half(const void* p, size_t n) {
+  std::vector<uint16_t> h(n);
+  CK(hipMemcpy(h.data(), p, n * 2, hipMemcpyDeviceToHost));
+  return h;
+}
+static float h2f(uint16_t b) { _Float16 v; memcpy(&v, &b, 2); return (float)v; }
+
+struct Ctx {
+  int K, N, NG, KB, sets;
+  std::vector<void*> packed;
+  void *x, *y, *yref;
+  hipStream_t st;
+};
+
+static Ctx make_ctx(int K, int N, int sets) {
+  Ctx c; c.K = K; c.N = N; c.NG = (N + 15) / 16; c.KB = K / 128; c.sets = sets;
+  const size_t pbytes = awq_repacked_bytes(K, N, 128, AWQ_DTYPE_F16);
+  if (!pbytes) { fprintf(stderr, "shape not supported\n"); exit(1); }
+  CK(hipStreamCreate(&c.st));
+  int32_t *qw, *qz; void* sc;
+  CK(hipMalloc(&qw, (size_t)K * N / 8 * 4)); CK(hipMalloc(&qz, (size_t)(K / 128) * N / 8 * 4)); CK(hipMalloc(&sc, (size_t)(K / 128) * N * 2));
+  fill_u32(qz, (size_t)(K / 128) * N / 8); fill_half(sc, (size_t)(K / 128) * N, 0.005f, 0.02f);
+  c.packed.resize(sets);
+  for (int i = 0; i < sets; ++i) {
+    CK(hipMalloc(&c.packed[i], pbytes));
+    fill_u32(qw, (size_t)K * N / 8);
+    if (awq_repack(qw, sc, qz, c.packed[i], K, N, 128, AWQ_DTYPE_F16, c.st)) { fprintf(stderr, "repack failed\n"); exit(1); }
+    CK(hipStreamSynchronize(c.st));
+  }
+  CK(hipFree(qw)); CK(hipFree(qz)); CK(hipFree(sc));
+  CK(hipMalloc(&c.x, (size_t)K * 2)); fill_half(c.x, K, -1.f, 1.f);
+  CK(hipMalloc(&c.y, (size_t)N * 2)); CK(hipMalloc(&c.yref, (size_t)N * 2));
+  return c;
+}
+
+static LabArgs lab_args(const Ctx& c, int set, unsigned long long* dbg) {
+  LabArgs a;
+  a.x = (const uint16_t*)c.x; a.qw_r = (const u32x4_t*)c.packed[set];
+  a.zs_r = (const uint32_t*)c.packed[set] + (size_t)c.NG * c.KB * 256;
+  a.y = (uint16_t*)c.y; a.M = 1; a.K = c.K; a.N = c.N; a.NG = c.NG; a.KB = c.KB; a.dbg = dbg;
+  return a;
+}
+
+static size_t lab_lds(const Variant& v, int KB) { const int T = KB / v.W; return (size_t)v.W * 16 * v.G * 4 + (size_t)v.W * ((T * 128 + 8) * 2 + v.G * T * 64); }
+
+static double time_graph(const Ctx& c, int iters, const std::function<void(int)>& launch) {
+  for (int i = 0; i < 2 * c.sets; ++i) launch(i);
+  CK(hipStreamSynchronize(c.st));
+  hipGraph_t graph; hipGraphExec_t exec;
+  CK(hipStreamBeginCapture(c.st, hipStreamCaptureModeGlobal));
+  for (int i = 0; i < c.sets; ++i) launch(i);
+  CK(hipStreamEndCapture(c.st, &graph));
+  CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  const int reps = (iters + c.sets - 1) / c.sets;
+  for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(exec, c.st));
+  CK(hipStreamSynchronize(c.st));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0, c.st));
+  for (int i = 0; i < reps; ++i) CK(hipGraphLaunch(exec, c.st));
+  CK(hipEventRecord(e1, c.st));
+  CK(hipStreamSynchronize(c.st));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  CK(hipGraphExecDestroy(exec)); CK(hipGraphDestroy(graph));
+  CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+  return ms * 1e3 / (reps * c.sets);
+}
+
+static int cmd_time(int argc, char** argv) {
+  const int K = atoi(argv[2]), N = atoi(argv[3]);
+  const int sets = argc > 4 ? atoi(argv[4]) : 16, iters = argc > 5 ? atoi(argv[5]) : 400;
+  const char* filter = argc > 6 ? argv[6] : "";
+  if (K != 4096) { fprintf(stderr, "lab variants are instantiated for K = 4096\n"); return 2; }
+  Ctx c = make_ctx(K, N, sets);
+  const double bytes = (double)K * N / 2 + (double)(K / 128) * N / 2 + (double)(K / 128) * N * 2 + K * 2 + N * 2;
+  // library reference
+  {
+    auto launch = [&](int i) { if (awq_gemm_repacked(c.x, K, c.packed[i % sets], nullptr, c.yref, 1, K, N, 128, AWQ_DTYPE_F16, c.st)) exit(1); };
+    const double us = time_graph(c, iters, launch);
+    printf("%-28s %8.3f us  %7.1f GB/s  frac8T %.3f\n", "library awq_gemm_repacked", us, bytes / us / 1e3, bytes / us / 1e3 / 8000.0);
+  }
+  for (const Variant& v : kVariants4096) {
+    if (!strstr(v.name, filter)) continue;
+    const int nwg = (c.NG + v.G - 1) / v.G;
+    const size_t lds = lab_lds(v, c.KB);
+    // correctness on set 0
+    CK(hipMemsetAsync(c.y, 0xff, (size_t)N * 2, c.st));
+    if (awq_gemm_repacked(c.x, K, c.packed[0], nullptr, c.yref, 1, K, N, 128, AWQ_DTYPE_F16, c.st)) return 1;
+    v.launch(lab_args(c, 0, nullptr), nwg, lds, c.st);
+    CK(hipStreamSynchronize(c.st));
+    CK(hipGetLastError());
+    std::string verdict = "-";
+    if (v.exact_compute) {
+      auto got = d2h_half(c.y, N), want = d2h_half(c.yref, N);
+      int same = 0; double maxd = 0;
+      for (int n = 0; n < N; ++n) { same += got[n] == want[n]; maxd = std::max(maxd, (double)fabsf(h2f(got[n]) - h2f(want[n]))); }
+      char b[96]; snprintf(b, sizeof b, "bit-equal %d/%d maxdiff %.4g", same, N, maxd); verdict = b;
+    }
+    auto launch = [&](int i) { v.launch(lab_args(c, i % sets, nullptr), nwg, lds, c.st); };
+    const double us = time_graph(c, iters, launch);
+    printf("%-28s %8.3f us  %7.1f GB/s  frac8T %.3f  nwg %d lds %zu  %s\n", v.name, us, bytes / us / 1e3, bytes / us / 1e3 / 8000.0, nwg, lds, verdict.c_str());
+    fflush(stdout);
+  }
+  return 0;
+}
+
+static int cmd_stamps(int argc, char** argv) {
+  const int K = atoi(argv[2]), N = atoi(argv[3]);
+  const char* name = argv[4];
+  const int sets = argc > 5 ? atoi(argv[5]) : 16;
+  const Variant* v = nullptr;
+  for (const Variant& vv : kVariants4096) if (!strcmp(vv.name, name)) v = &vv;
+  if (!v) { fprintf(stderr, "no such variant\n"); return 2; }
+  Ctx c = make_ctx(K, N, sets);
+  const int nwg = (c.NG + v->G - 1) / v->G;
+  const size_t lds = lab_lds(*v, c.KB), nst = (size_t)nwg * v->W * 8;
+  unsigned long long* dbg; CK(hipMalloc(&dbg, nst * 8));
+  // back-to-back train: the stamped launch is the last of a run of launches (steady state), stamps only in that one
+  std::vector<unsigned long long> h(nst);
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipMemsetAsync(dbg, 0, nst * 8, c.st));
+    for (int i = 0; i < sets; ++i) v->launch(lab_args(c, i, i == sets - 1 ? dbg : nullptr), nwg, lds, c.st);
+    CK(hipStreamSynchronize(c.st));
+  }
+  CK(hipMemcpy(h.data(), dbg, nst * 8, hipMemcpyDeviceToHost));
+  unsigned long long t0 = ~0ull;
+  for (size_t i = 0; i < nst; i += 8) if (h[i] && h[i] < t0) t0 = h[i];
+  const char* names[7] = {"start", "loads issued", "first load computed", "half computed", "all computed", "after barrier", "stored"};
+  printf("stamps %s: %d workgroups x %d waves, us after the first wave started (train of %d launches, last one stamped)\n", name, nwg, v->W, sets);
+  for (int slot = 0; slot < 7; ++slot) {
+    std::vector<double> all;
+    for (size_t i = 0; i < nst; i += 8) if (h[i + slot]) all.push_back((double)(h[i + slot] - t0) * 0.01);
+    if (all.empty()) continue;
+    std::sort(all.begin(), all.end());
+    printf("  %-22s n=%5zu  min %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f\n", names[slot], all.size(), all.front(), all[all.size() / 10], all[all.size() / 2],
+           all[all.size() * 9 / 10], all.back());
+  }
+  // by wave index: median of 'first load computed' and 'all computed'
+  printf("  per wave index (median over workgroups): first-computed / all-computed\n   ");
+  for (int w = 0; w < v->W; ++w) {
+    std::vector<double> a2, a4;
+    for (int b = 0; b < nwg; ++b) {
+      const size_t i = ((size_t)b * v->W + w) * 8;
+      if (h[i + 2]) a2.push_back((double)(h[i + 2] - t0) * 0.01);
+      if (h[i + 4]) a4.push_back((double)(h[i + 4] - t0) * 0.01);
+    }
+    std::sort(a2.begin(), a2.end()); std::sort(a4.begin(), a4.end());
+    if (!a2.empty()) printf(" w%d %.2f/%.2f", w, a2[a2.size() / 2], a4[a4.size() / 2]);
+  }
+  printf("\n");
+  // one workgroup in full
+  const int b = nwg / 2;
+  printf("  workgroup %d, per wave: start issued first half all barrier stored\n", b);
+  for (int w = 0; w < v->W; ++w) {
+    printf("    w%-2d", w);
+    for (int s = 0; s < 7; ++s) { const unsigned long long t = h[((size_t)b * v->W + w) * 8 + s]; printf(" %6.2f", t ? (double)(t - t0) * 0.01 : -1.0); }
+    printf("\n");
+  }
+  return 0;
+}
+
+
+// VALU / MFMA issue-rate microbenchmark: the dequantise + MFMA sequence of one 1 KiB load (4 dwords per lane), on
+// register data, repeated; W waves per workgroup (W / 4 per SIMD); reports shader cycles per dword per wave.
+template <int MODE>   // 0 full, 1 no MFMA, 2 MFMA only, 3 only the 4 v_pk_mul per dword, 4 only the and_or + shift
+__global__ void ubench_kernel(uint32_t* out, unsigned long long* cyc, int iters, uint32_t seed) {
+  const int lane = threadIdx.x & 63;
+  uint32_t mlo = kLoNib, mhi = kHiNib, magic = kMagicF16;
+  asm volatile("" : "+s"(mlo), "+s"(mhi));
+  asm volatile("" : "+v"(magic));
+  u32x4_t w = {seed * 2654435761u + lane, seed ^ (lane * 40503u), seed + 77u * lane, seed * 3u + lane};
+  uint32_t zsv = 0x64082000u + (lane & 7);
+  const half2_t c960 = {(half_t)960.f, (half_t)960.f};
+  const half2_t sixteenth = {(half_t)0.0625f, (half_t)0.0625f};
+  u32x4_t xa[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) xa[d] = (u32x4_t){0x3c003c00u + lane, 0x3c003c00u, 0x38003c00u, 0x3c003800u + d};
+  float4_t acc = {0.f, 0.f, 0.f, 0.f};
+  u32x4_t sink = {0u, 0u, 0u, 0u};
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+    const half2_t zh = as_h2(zsv);
+    const half2_t s2 = __builtin_shufflevector(zh, zh, 0, 0);
+    const half2_t z1024 = __builtin_shufflevector(zh, zh, 1, 1);
+    const half2_t z64 = z1024 - c960;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t ww = w[d], w8 = ww >> 8;
+      u32x4_t frag;
+      if constexpr (MODE == 2) frag = (u32x4_t){ww, ww, ww, ww};
+      else if constexpr (MODE == 3) {
+        frag = (u32x4_t){as_u32(as_h2(ww) * s2), as_u32(as_h2(ww ^ 1u) * s2), as_u32(as_h2(ww ^ 2u) * s2), as_u32(as_h2(ww ^ 3u) * s2)};
+      } else if constexpr (MODE == 4) {
+        frag = (u32x4_t){(ww & mlo) | magic, (ww & mhi) | magic, (w8 & mlo) | magic, (w8 & mhi) | magic};
+      } else {
+        const half2_t d0 = as_h2((ww & mlo) | magic) - z1024;
+        const half2_t d1 = __builtin_elementwise_fma(as_h2((ww & mhi) | magic), sixteenth, -z64);
+        const half2_t d2 = as_h2((w8 & mlo) | magic) - z1024;
+        const half2_t d3 = __builtin_elementwise_fma(as_h2((w8 & mhi) | magic), sixteenth, -z64);
+        frag = (u32x4_t){as_u32(d0 * s2), as_u32(d1 * s2), as_u32(d2 * s2), as_u32(d3 * s2)};
+      }
+      if constexpr (MODE == 1 || MODE == 3 || MODE == 4) { sink[0] ^= frag[0]; sink[1] ^= frag[1]; sink[2] ^= frag[2]; sink[3] ^= frag[3]; }
+      else acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, xa[d]), __builtin_bit_cast(half8_t, frag), acc, 0, 0, 0);
+    }
+    // make the next iteration's inputs depend on nothing expensive, but keep them opaque
+    asm volatile("" : "+v"(w), "+v"(zsv));
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = __builtin_bit_cast(uint32_t, acc[0]) ^ sink[0] ^ sink[1] ^ sink[2] ^ sink[3];
+}
+
+static int cmd_ubench(int, char**) {
+  const int iters = 2000, nwg = 256;
+  uint32_t* out; unsigned long long* cyc;
+  CK(hipMalloc(&out, (size_t)nwg * 1024 * 4)); CK(hipMalloc(&cyc, (size_t)nwg * 16 * 8));
+  const char* names[5] = {"full (13 VALU + MFMA)", "no MFMA (13 VALU + 4 xor)", "MFMA only", "4 v_pk_mul + 4 xor", "4 and_or + shift + 4 xor"};
+  for (int mode = 0; mode < 5; ++mode)
+    for (int W : {4, 8, 16}) {
+      for (int rep = 0; rep < 2; ++rep) {
+        switch (mode) {
+          case 0: hipLaunchKernelGGL(ubench_kernel<0>, dim3(nwg), dim3(W * 64), 0, 0, out, cyc, iters, 12345u); break;
+          case 1: hipLaunchKernelGGL(ubench_kernel<1>, dim3(nwg), dim3(W * 64), 0, 0, out, cyc, iters, 12345u); break;
+          case 2: hipLaunchKernelGGL(ubench_kernel<2>, dim3(nwg), dim3(W * 64), 0, 0, out, cyc, iters, 12345u); break;
+          case 3: hipLaunchKernelGGL(ubench_kernel<3>, dim3(nwg), dim3(W * 64), 0, 0, out, cyc, iters, 12345u); break;
+          default: hipLaunchKernelGGL(ubench_kernel<4>, dim3(nwg), dim3(W * 64), 0, 0, out, cyc, iters, 12345u); break;
+        }
+        CK(hipDeviceSynchronize());
+      }
+      std::vector<unsigned long long> h((size_t)nwg * W);
+      CK(hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost));
+      std::sort(h.begin(), h.end());
+      const double med = (double)h[h.size() / 2] / (iters * 4.0);
+      printf("ubench %-28s waves/WG %2d (%d per SIMD): %7.1f s_memtime ticks per dword per wave -> %6.1f per dword per SIMD\n", names[mode], W, W / 4, med, med / (W / 4));
+    }
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 2 && std::string(argv[1]) == "ubench") return cmd_ubench(argc, argv);
+  if (argc < 4) { fprintf(stderr, "usage: gemv_lab time K N [sets] [iters] [filter] | stamps K N variant [sets]\n"); return 2; }
+  std::string cmd = argv[1];
+  if (cmd == "time") return cmd_time(argc, argv);
+  if (cmd == "stamps" && argc >= 5) return cmd_stamps(argc, argv);
+  return 2;
+}
