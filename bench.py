@@ -5,48 +5,69 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], the decode shape): awq_gemm at M = 1, K = 4096, N = 11008,
-g = 128, fp16.  One STEP = one column-parallel AWQ linear followed by one row-parallel AWQ linear,
-each rank holding a full 4096 x 11008 shard (weak scaling: the TP=N layer is N times wider), i.e.
-two fused int4 GEMV launches per rank and, for N > 1, one RCCL all-reduce of the [M, 11008] fp16
-partial sums.  The linears are this package's AWQLinearMethod as deployed: at load time
-(process_weights_after_loading) the weights get a one-time MFMA-fragment-major copy and decode batches
-run the kernel on that copy; the drop-in op on the checkpoint layout (`sgl_kernel.awq_gemm`) is timed
-beside it and reported as `config.awq_gemm_op_checkpoint_layout`.  Weights rotate through `--sets` distinct copies (> 2x the 256 MiB Infinity Cache) so
-the stream comes from HBM, not from cache; the cache-hot number is reported beside it.  Steps are
-replayed from a captured HIP graph (the decode path of the reference replays graphs too), so the
-timed region contains exactly K steps of device work and no Python.
+Headline workload (BASELINE.json configs[1], the decode shape): awq_gemm at M = 1, K = 4096, N = 11008,
+g = 128, fp16.  One STEP = one column-parallel AWQ linear followed by one row-parallel AWQ linear, i.e.
+two fused int4 GEMV launches per rank and, for N > 1, one RCCL all-reduce of the [M, N_out] fp16 partial sums.
+  --scaling weak   (default) every rank holds a full 4096 x 11008 shard (the TP = N layer is N times wider);
+  --scaling strong the ONE 4096 x 11008 layer is sharded as SURVEY §8(e) lists: column-parallel N / tp
+                   (11008, 5504, 2752, 1376 columns), row-parallel K / tp (4096 ... 512 rows, whole groups),
+                   all-reduce payload [M, 11008];
+  --shapes 70b-tp8 the four per-rank linears of Llama-2-70B at TP = 8 (BASELINE configs[4]): qkv 8192 -> 1280,
+                   o 1024 -> 8192 (+ AR), gate_up 8192 -> 7168, down 3584 -> 8192 (+ AR); with fewer than 8 ranks the
+                   per-rank shapes are kept and the all-reduce runs over the ranks present.
+The linears are this package's AWQLinearMethod as deployed: at load time (process_weights_after_loading) the
+weights get a one-time MFMA-fragment-major copy and decode batches run the kernel on that copy.  Weights rotate
+through `--sets` distinct copies (> 2x the 256 MiB Infinity Cache) so the stream comes from HBM, not from cache.
+Steps are replayed from a captured HIP graph (the decode path of the reference replays graphs too), so the timed
+region contains exactly K steps of device work and no Python.
 
-Prints ONE JSON line (rank 0).  `value` is whole-job algorithmic GB/s: bytes every rank must move
-(packed weight + activations + outputs = 23,455,232 B per GEMV) divided by the slowest rank's time.
-`roofline` prices the dominant kernel (the fused GEMV) against 8 TB/s; `cpu_baseline` times the
-reference's CPU form of the same linear (eager PyTorch dequantise + matmul) on this host.
+Prints ONE JSON line (rank 0).  `value` is whole-job algorithmic GB/s: bytes every rank must move (packed weight +
+activations + outputs = 23,455,232 B per GEMV at the headline shape) divided by the slowest rank's wall time over
+the K timed steps (barrier + synchronize on both sides).  `roofline` prices the dominant kernel (the fused GEMV)
+against 8 TB/s from HIP events around the same K steps (all K steps are one graph replay, kernel boundaries included);
+`cpu_baseline` times the reference's CPU form of the same linear on this host.
+
+At N = 1 the same line also carries the rest of BASELINE.json's metric, each measured in this run:
+  `prefill`        awq_gemm at M = 2048 (configs[2]): us, TFLOP/s, roofline against 2.5 PFLOP/s dense fp16;
+  `dequantize`     awq_dequantize 4096 x 11008 (configs[0]'s op on the GPU): us, GB/s against 113,602,560 B;
+  `awq_gemm_op`    the drop-in `sgl_kernel.awq_gemm` op on the checkpoint tensors (M = 1 and M = 2048);
+  `decode_7b_tp1`  Llama-2-7B-AWQ decode tok/s at batch 1 and 32 (configs[3]), median-latency method of the
+                   reference's bench_one_batch.py:497-623.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import re
+import statistics
 import subprocess
 import sys
+import tempfile
 import time
 
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs between processes on this host driver
+# dmabuf IPC between processes: the platform this runs on documents it as required for RCCL / cross-process GPU
+# memory sharing on its host driver (legacy IPC fails with hipIpcGetMemHandle: invalid argument); harmless at N = 1
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 K_DIM, N_DIM, GROUP = 4096, 11008, 128
-HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-# HBM bytes per M=1 launch from the PMC counters (separate rocprofv3 --pmc passes of tools/kbench, files
-# profiles/r01_pmc_{fetch,write}_size_gemv_m1.csv): FETCH_SIZE 11,870.5 KiB x 2 (gfx950 reports half of a
-# wide coalesced read stream; calibrated on a 22.5 MB linear read) + WRITE_SIZE 513.75 KiB
-PMC_TRAFFIC_BYTES_M1_CHECKPOINT_LAYOUT = int((2 * 11870.5 + 513.75) * 1024)   # gemm_skinny_kernel (awq_gemm op)
-PMC_TRAFFIC_BYTES_M1 = int((2 * 11812.0 + 21.5625) * 1024)                     # gemv_repacked_kernel (profiles/r01_pmc_*_repacked_m1.csv)
-MFMA_PEAK_TFLOPS = 2500.0       # dense fp16/bf16
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBPS = 6290.0          # ... 6.29 TB/s measured (float4 copy), the practical ceiling of a streaming kernel
+MFMA_PEAK_TFLOPS = 2500.0       # dense fp16 / bf16
+# per-rank linears of Llama-2-70B at TP = 8 (hidden 8192, 64 q / 8 kv heads of 128, intermediate 28672): (kind, K, N)
+SHAPES_70B_TP8 = [("col", 8192, 1280), ("row", 1024, 8192), ("col", 8192, 7168), ("row", 3584, 8192)]
+
+
+def linear_bytes(M: int, K: int, N: int, g: int = GROUP) -> int:
+    """Algorithmic bytes of one AWQ linear launch: packed weight + zeros + scales + x + y (fp16)."""
+    return K * N // 2 + (K // g) * (N // 2) + (K // g) * N * 2 + M * K * 2 + M * N * 2
 
 
 def algorithmic_bytes(M: int) -> int:
-    w = K_DIM * N_DIM // 2 + (K_DIM // GROUP) * (N_DIM // 2) + (K_DIM // GROUP) * N_DIM * 2   # 23,425,024
-    return w + M * K_DIM * 2 + M * N_DIM * 2
+    return linear_bytes(M, K_DIM, N_DIM)          # 23,455,232 at M = 1
 
 
 def parse_args():
@@ -54,10 +75,14 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--m", type=int, default=1, help="rows of the activation (1 = decode shape; 2048 = prefill shape)")
+    ap.add_argument("--m", type=int, default=1, help="rows of the activation of the headline workload (1 = decode shape)")
     ap.add_argument("--sets", type=int, default=16, help="distinct weight sets rotated through (each 2 x 23.4 MB)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--shapes", choices=["baseline", "70b-tp8"], default="baseline")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--sections", default="prefill,dequantize,op,decode,large",
+                    help="extra records measured at N = 1 beside the headline (comma list; '' = none)")
     return ap.parse_args()
 
 
@@ -94,6 +119,59 @@ def cpu_baseline(budget_s: float, M: int):
                       f"{el:.1f} s on {torch.get_num_threads()} threads ({os.cpu_count()} logical CPUs)"}
 
 
+def pmc_traffic(kernel_substr: str):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/*pmc_fetch_size*gemv*m1.csv and
+    the matching write_size file; newest round first): 2 x FETCH_SIZE (gfx950 reports half of a wide coalesced read
+    stream, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, both in KiB per dispatch.  None if no committed pass has the kernel."""
+    def mean_counter(path, counter):
+        vals = []
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                if row.get("Counter_Name") == counter and kernel_substr in row.get("Kernel_Name", ""):
+                    vals.append(float(row["Counter_Value"]))
+        return sum(vals) / len(vals) if vals else None
+
+    for fetch_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_size_*m1*.csv")), reverse=True):
+        write_path = fetch_path.replace("fetch_size", "write_size")
+        if not os.path.exists(write_path):
+            continue
+        fk, wk = mean_counter(fetch_path, "FETCH_SIZE"), mean_counter(write_path, "WRITE_SIZE")
+        if fk is not None and wk is not None:
+            return int((2 * fk + wk) * 1024), [os.path.relpath(fetch_path, ROOT), os.path.relpath(write_path, ROOT)]
+    return None, []
+
+
+def rccl_summary(log_glob: str):
+    """What RCCL said it chose (NCCL_DEBUG=INFO into per-process files): version, transports, channels, and any
+    algorithm / protocol lines.  Best effort: the exact wording differs between RCCL releases."""
+    info = {"version": None, "transports": [], "channels": None, "algo_proto": [], "lines_seen": 0}
+    transports, algos = set(), []
+    for path in sorted(glob.glob(log_glob)):
+        try:
+            with open(path, errors="replace") as f:
+                for line in f:
+                    info["lines_seen"] += 1
+                    m = re.search(r"(RCCL|NCCL) version ([^\s]+)", line)
+                    if m and not info["version"]:
+                        info["version"] = f"{m.group(1)} {m.group(2)}"
+                    m = re.search(r"via (P2P|SHM|NET)/([A-Za-z0-9_]+)", line)
+                    if m:
+                        transports.add(f"{m.group(1)}/{m.group(2)}")
+                    m = re.search(r"(\d+) coll channels", line)
+                    if m:
+                        info["channels"] = int(m.group(1))
+                    m = re.search(r"[Aa]lgo(?:rithm)?\s*[:=]?\s*(\w+).*?[Pp]roto(?:col)?\s*[:=]?\s*(\w+)", line)
+                    if m:
+                        ap = f"{m.group(1)}/{m.group(2)}"
+                        if ap not in algos:
+                            algos.append(ap)
+        except OSError:
+            pass
+    info["transports"] = sorted(transports)
+    info["algo_proto"] = algos[:8]
+    return info
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,6 +179,15 @@ def main():
         respawn_under_torchrun(args)          # before anything touches the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    test_backend = os.environ.get("BENCH_TEST_BACKEND")
+    rccl_log = None
+    if world > 1 and not test_backend:
+        # ask RCCL what it picks; into files, not onto the JSON line's stdout (INIT + tuning + per-collective choice; a
+        # graph replay logs nothing, so the timed region is unaffected unless capture falls back to eager launches)
+        rccl_log = os.path.join(tempfile.gettempdir(), f"awq_bench_rccl_{os.environ.get('MASTER_PORT', '0')}")
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL,TUNING,GRAPH")
+        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log + ".%h.%p.log")
 
     import numpy as np
     import torch
@@ -112,10 +199,14 @@ def main():
     from sglang_awq_amd.linear import ColumnParallelLinear, RowParallelLinear
 
     # BENCH_TEST_BACKEND=gloo + BENCH_TEST_ONE_DEVICE=1: rehearsal of the N > 1 code path on a one-GPU box (every
-    # rank on device 0, collectives over gloo, no graph capture).  Never used for reported numbers.
-    test_backend = os.environ.get("BENCH_TEST_BACKEND")
-    dev = torch.device("cuda", 0 if os.environ.get("BENCH_TEST_ONE_DEVICE") else local_rank)
-    torch.cuda.set_device(dev)
+    # rank on device 0, collectives over gloo, no graph capture).  BENCH_TEST_CPU=1: the same on CPU tensors with the
+    # kernels stubbed out (shapes, sharding and collectives only; tests/test_tp_cpu.py).  Never used for reported numbers.
+    cpu_rehearsal = bool(os.environ.get("BENCH_TEST_CPU"))
+    if cpu_rehearsal:
+        dev = torch.device("cpu")
+    else:
+        dev = torch.device("cuda", 0 if os.environ.get("BENCH_TEST_ONE_DEVICE") else local_rank)
+        torch.cuda.set_device(dev)
     if world > 1:
         tp = init_tensor_parallel(backend=test_backend or "nccl", device=None if test_backend else dev)
     else:
@@ -123,146 +214,250 @@ def main():
     M = args.m
     cfg = AWQConfig(weight_bits=4, group_size=GROUP, zero_point=True)
 
-    # ---- synthetic layers: per-rank shard = the BASELINE shape (weak scaling) -------------------
-    def make_layer(kind, seed, checked):
+    def sync():
+        if not cpu_rehearsal:
+            torch.cuda.synchronize()
+
+    # ---- which linears one step runs on this rank: (kind, K_total, N_total) as the TP layer sees them -----------
+    if args.shapes == "70b-tp8":
+        # per-rank shapes are those of TP = 8; the layer objects are built tp.world_size wide so the sharding code runs
+        plan = [(kind, K * (tp.world_size if kind == "row" else 1), N * (tp.world_size if kind == "col" else 1))
+                for kind, K, N in SHAPES_70B_TP8]
+        scaling = "weak"
+    elif args.scaling == "strong":
+        if N_DIM % (8 * tp.world_size) or K_DIM % (GROUP * tp.world_size):
+            raise SystemExit(f"strong scaling of {K_DIM} x {N_DIM} g{GROUP} is not legal at tp={tp.world_size} (awq.py:372-385)")
+        plan = [("col", K_DIM, N_DIM), ("row", K_DIM, N_DIM)]
+        scaling = "strong"
+    else:
+        plan = [("col", K_DIM, N_DIM * tp.world_size), ("row", K_DIM * tp.world_size, N_DIM)]
+        scaling = "weak"
+    rank_shapes = [(kind, K // (tp.world_size if kind == "row" else 1), N // (tp.world_size if kind == "col" else 1)) for kind, K, N in plan]
+    bytes_step_rank = sum(linear_bytes(M, K, N) for _, K, N in rank_shapes)
+    flops_step_rank = sum(2 * M * K * N for _, K, N in rank_shapes)
+    ar_payloads = [M * N * 2 for kind, _, N in plan if kind == "row"] if tp.world_size > 1 else []
+
+    def make_layer(kind, K, N, seed, checked):
         if kind == "col":
-            layer = ColumnParallelLinear(K_DIM, N_DIM * tp.world_size, bias=False, quant_config=cfg, params_dtype=torch.float16)
+            layer = ColumnParallelLinear(K, N, bias=False, quant_config=cfg, params_dtype=torch.float16)
         else:
-            layer = RowParallelLinear(K_DIM * tp.world_size, N_DIM, bias=False, quant_config=cfg, params_dtype=torch.float16)
+            layer = RowParallelLinear(K, N, bias=False, quant_config=cfg, params_dtype=torch.float16)
         layer.to(dev)
         if checked:
-            qw, s, qz = synth.make_awq_weights(K_DIM, N_DIM, GROUP, "f16", "A", seed)
+            qw, s, qz = synth.make_awq_weights(layer.qweight.shape[0], layer.qweight.shape[1] * 8, GROUP, "f16", "A", seed)
             layer.qweight.data.copy_(torch.from_numpy(qw)); layer.scales.data.copy_(torch.from_numpy(s)); layer.qzeros.data.copy_(torch.from_numpy(qz))
         else:
             g = torch.Generator(device=dev); g.manual_seed(seed)
             layer.qweight.data.copy_(torch.randint(-2 ** 31, 2 ** 31 - 1, layer.qweight.shape, dtype=torch.int64, device=dev, generator=g).to(torch.int32))
             layer.qzeros.data.copy_(torch.randint(-2 ** 31, 2 ** 31 - 1, layer.qzeros.shape, dtype=torch.int64, device=dev, generator=g).to(torch.int32))
             layer.scales.data.copy_((0.005 + 0.015 * torch.rand(layer.scales.shape, device=dev, generator=g)).half())
-        layer.process_weights_after_loading()
+        if cpu_rehearsal:
+            layer.quant_method.apply = lambda lyr, x, bias=None: torch.zeros(x.shape[:-1] + (lyr.qweight.shape[1] * 8,), dtype=x.dtype)
+        else:
+            layer.process_weights_after_loading()
         return layer
 
     sets = max(1, args.sets)
-    cols = [make_layer("col", 1234 + 2 * i, i == 0) for i in range(sets)]
-    rows = [make_layer("row", 1235 + 2 * i, i == 0) for i in range(sets)]
-    x_np = synth.make_activations(M, K_DIM, "f16", "A", 1234 + rank)
-    x_col = torch.from_numpy(x_np.copy()).to(dev)
-    x_row = torch.from_numpy(synth.make_activations(M, K_DIM, "f16", "A", 4321 + rank).copy()).to(dev)
+    layer_sets = [[make_layer(kind, K, N, 1234 + 16 * i + j, i == 0 and j == 0) for j, (kind, K, N) in enumerate(plan)] for i in range(sets)]
 
-    # ---- parity spot-check of set 0 against the oracle (rank 0; the checker, not the measured path)
-    if rank == 0:
+    def make_x(rows):
+        xs = []
+        for j, (kind, K, N) in enumerate(rank_shapes):
+            xs.append(torch.from_numpy(synth.make_activations(rows, K, "f16", "A", 1234 + 3087 * j + rank).copy()).to(dev))
+        return xs
+
+    xs = make_x(M)
+
+    # ---- parity spot-check of set 0's first linear against the oracle (rank 0; the checker, not the measured path)
+    if rank == 0 and not cpu_rehearsal:
         from oracle import c_oracle
 
-        y = cols[0](x_col)[0]
-        qw, s, qz = synth.make_awq_weights(K_DIM, N_DIM, GROUP, "f16", "A", 1234)
-        Mc = min(M, 2)
-        _, exact = c_oracle.gemm(x_np[:Mc], qw, s, qz, want_exact=True)
-        got = y[:Mc].float().cpu().numpy().astype(np.float64)
-        ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(exact), 2.0 ** -14))) - 10)
-        if not np.all(np.abs(got - exact) <= 0.5 * ulp + 1e-3):
-            raise SystemExit("bench: GPU result does not match the oracle; refusing to time a wrong kernel")
+        kind0, K0, N0 = rank_shapes[0]
+        y = layer_sets[0][0](xs[0])[0]
+        if tp.world_size == 1:
+            qw, s, qz = synth.make_awq_weights(K0, N0, GROUP, "f16", "A", 1234)
+            Mc = min(M, 2)
+            _, exact = c_oracle.gemm(xs[0][:Mc].cpu().numpy(), qw, s, qz, want_exact=True)
+            got = y[:Mc].float().cpu().numpy().astype(np.float64)
+            ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(exact), 2.0 ** -14))) - 10)
+            if not np.all(np.abs(got - exact) <= 0.5 * ulp + 1e-3):
+                raise SystemExit("bench: GPU result does not match the oracle; refusing to time a wrong kernel")
 
-    def step(i):
-        c, r = cols[i % sets], rows[i % sets]
-        c(x_col)
-        r(x_row)                      # includes the all-reduce when tp > 1
+    def step(i, layers=None, inputs=None):
+        layers = layers if layers is not None else layer_sets[i % sets]
+        inputs = inputs if inputs is not None else xs
+        for layer, x in zip(layers, inputs):
+            layer(x)                      # a row-parallel linear includes the all-reduce when tp > 1
 
-    # ---- graphs of `sets` steps (one pass over every weight set) + a remainder graph ------------
-    use_graph = not args.no_graph and not test_backend
+    # ---- graphs: one holding all K timed steps (a single replay in the timed region), one for the warm-up -------
+    use_graph = not args.no_graph and not test_backend and not cpu_rehearsal
+    capture_error = None
     graphs = {}
 
-    def capture(n):
+    def capture(n, fn=step):
         g = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread may touch the runtime while this thread captures (N > 1)
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             for i in range(n):
-                step(i)
+                fn(i)
         return g
+
+    MAX_GRAPH_STEPS = 256
 
     def run_steps(n):
         if not use_graph:
             for i in range(n):
                 step(i)
             return
-        full, rem = divmod(n, sets)
-        for _ in range(full):
-            graphs[sets].replay()
-        if rem:
-            graphs[rem].replay()
+        while n > 0:
+            k = n if n in graphs else (MAX_GRAPH_STEPS if n >= MAX_GRAPH_STEPS and MAX_GRAPH_STEPS in graphs else sets if n >= sets and sets in graphs else 1)
+            graphs[k].replay()
+            n -= k
 
     for i in range(min(sets, 4)):
         step(i)                        # eager warm-up: workspace allocation, RCCL communicator setup
-    torch.cuda.synchronize()
+    sync()
     if use_graph:
         try:
-            graphs[sets] = capture(sets)
-            for n in {args.steps % sets, args.warmup % sets} - {0}:
+            for n in sorted({min(args.steps, MAX_GRAPH_STEPS), min(max(args.warmup, 1), MAX_GRAPH_STEPS), sets, 1}):
                 graphs[n] = capture(n)
         except Exception as e:         # e.g. a collective that cannot be captured on this stack
+            capture_error = repr(e)
             if rank == 0:
                 print(f"bench: graph capture failed ({e!r}); falling back to eager launches", file=sys.stderr)
             use_graph = False
             graphs.clear()
-            torch.cuda.synchronize()
+            sync()
 
-    def timed(n):
-        """barrier + sync, n steps, sync + barrier; returns (wall seconds, HIP-event seconds)."""
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        tp.barrier(); torch.cuda.synchronize()
+
+    def timed_wall(n):
+        """The contract's timed region: barrier + synchronize, n steps, synchronize + barrier; wall seconds."""
+        tp.barrier(); sync()
         t0 = time.perf_counter()
-        e0.record()
         run_steps(n)
+        sync(); tp.barrier()
+        return time.perf_counter() - t0
+
+    def timed_events(n, runner=None):
+        """The same n steps between HIP events on the launch stream (torch's current stream): device time of the kernels
+        and their boundaries.  (Queuing the events behind a spin kernel, to keep the host's graph-launch latency out of
+        the interval, measured the same: 6.963 vs 6.956 us per launch at K = 20 — one graph replay holds all K steps.)"""
+        if cpu_rehearsal:
+            return float("nan")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tp.barrier(); sync()
+        e0.record()
+        (runner or run_steps)(n)
         e1.record()
-        torch.cuda.synchronize(); tp.barrier()
-        t1 = time.perf_counter()
-        return t1 - t0, e0.elapsed_time(e1) * 1e-3
+        sync()
+        return e0.elapsed_time(e1) * 1e-3
 
     run_steps(args.warmup)
-    wall, ev = timed(args.steps)
+    wall = timed_wall(args.steps)
+    ev = timed_events(args.steps)
     if world > 1:
-        tmax = torch.tensor([wall, ev], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([wall, ev if ev == ev else 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall, ev = float(tmax[0]), float(tmax[1])
 
+    sections = set(s for s in args.sections.split(",") if s) if (world == 1 and rank == 0 and not cpu_rehearsal and args.shapes == "baseline"
+                                                                 and args.scaling == "weak") else set()
+
+    def graph_time(fn_pass, launches_per_pass, min_launches, max_seconds=2.0):
+        """us per launch of `fn_pass` (a pass over the rotating weight sets) replayed from a graph between HIP events."""
+        fn_pass()
+        sync()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn_pass()
+        for _ in range(2):
+            g.replay()
+        sync()
+        reps = max(2, -(-min_launches // launches_per_pass))
+        t = timed_events(reps, lambda n: [g.replay() for _ in range(n)])
+        return t * 1e6 / (reps * launches_per_pass)
+
     # cache-hot variant: one weight set only (fits the 256 MiB Infinity Cache)
     hot = None
-    if rank == 0 and world == 1:
-        saved = (cols, rows, sets, dict(graphs))
-        cols, rows, sets = cols[:1], rows[:1], 1
-        graphs.clear()
-        if use_graph:
-            graphs[1] = capture(1)
-        run_steps(50)
-        _, ev_hot = timed(500)
-        hot = ev_hot / 500
-        cols, rows, sets, graphs = saved[0], saved[1], saved[2], saved[3]
+    if sections and M <= 64:
+        hot = graph_time(lambda: step(0), len(plan), 1000)
 
-    # the drop-in op on the checkpoint layout, same rotation of weight sets (N = 1 only)
-    op_us = None
-    if rank == 0 and world == 1 and (M <= 16 or M >= 1024):
-        def op_pass():
-            for i in range(sets):
-                ops.awq_gemm(x_col, cols[i].qweight, cols[i].scales, cols[i].qzeros, 1)
-        op_pass()
-        torch.cuda.synchronize()
-        g_op = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_op):
-            op_pass()
-        for _ in range(3):
-            g_op.replay()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        reps = max(1, (1000 if M <= 16 else 100) // sets)
-        for _ in range(reps):
-            g_op.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        op_us = e0.elapsed_time(e1) * 1e3 / (reps * sets)
+    # ---- prefill (BASELINE configs[2]): the same layers at M = 2048, MFMA-bound --------------------------------
+    prefill = None
+    if "prefill" in sections and M != 2048:
+        MP = 2048
+        xp = make_x(MP)
+        us = graph_time(lambda: [step(i, inputs=xp) for i in range(sets)], sets * len(plan), 300)
+        tf = 2 * MP * K_DIM * N_DIM / us / 1e6
+        prefill = {"workload": f"awq_gemm M={MP} K={K_DIM} N={N_DIM} g={GROUP} fp16 (BASELINE configs[2]) via AWQLinearMethod.apply",
+                   "kernel": "gemm_repacked_pipelined_kernel", "us_per_launch": round(us, 2), "tflops": round(tf, 1),
+                   "GBps": round(linear_bytes(MP, K_DIM, N_DIM) / us / 1e3, 1),
+                   "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None}}
+        del xp
+
+    # ---- awq_dequantize (the op of BASELINE configs[0], on the GPU): HBM-bound, 113,602,560 B per call ---------
+    dequant = None
+    if "dequantize" in sections:
+        cols = [ls[0] for ls in layer_sets]
+        nrot = min(sets, 8)                                    # 8 x (23.4 MB in + 90.2 MB out) of distinct buffers
+        outs = [torch.empty((K_DIM, N_DIM), dtype=torch.float16, device=dev) for _ in range(nrot)]
+        lib = ops._lib.load()
+        import ctypes
+
+        def dq_pass():
+            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            for i in range(nrot):
+                c = cols[i]
+                rc = lib.awq_dequantize(ops._vp(c.qweight), ops._vp(c.scales), ops._vp(c.qzeros), ops._vp(outs[i]), K_DIM, N_DIM, GROUP,
+                                        ops._lib.DTYPE_F16, st)
+                if rc:
+                    raise SystemExit(f"awq_dequantize failed: {rc}")
+        us = graph_time(dq_pass, nrot, 400)
+        nbytes = K_DIM * N_DIM // 2 + (K_DIM // GROUP) * (N_DIM // 2) + (K_DIM // GROUP) * N_DIM * 2 + K_DIM * N_DIM * 2   # 113,602,560
+        # spot check against the op's own output path (bit-equality with the oracle is the -m gpu tests' job)
+        w_op = ops.awq_dequantize(cols[0].qweight, cols[0].scales, cols[0].qzeros)
+        if not torch.equal(w_op, outs[0]):
+            raise SystemExit("bench: awq_dequantize C-ABI call and torch op disagree")
+        dequant = {"workload": f"awq_dequantize K={K_DIM} N={N_DIM} g={GROUP} fp16 (sgl_kernel.awq_dequantize; through the C ABI into preallocated outputs)",
+                   "kernel": "dequant_kernel", "us_per_launch": round(us, 2), "bytes": nbytes, "GBps": round(nbytes / us / 1e3, 1),
+                   "roofline": {"bound": "hbm", "achieved": round(nbytes / us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBPS, 4), "frac_of_measured_copy": round(nbytes / us / 1e3 / HBM_COPY_GBPS, 4),
+                                "traffic": None}}
+        del outs, w_op
+
+    # ---- the drop-in op `sgl_kernel.awq_gemm` on the checkpoint tensors, same rotation of weight sets -----------
+    op_rec = None
+    if "op" in sections:
+        cols = [ls[0] for ls in layer_sets]
+        op_rec = {"cache": ops.awq_gemm_cache_info()["enabled"]}
+        for rows in (1, 2048):
+            xo = make_x(rows)[0]
+
+            def op_pass():
+                for i in range(sets):
+                    ops.awq_gemm(xo, cols[i].qweight, cols[i].scales, cols[i].qzeros, 1)
+            us = graph_time(op_pass, sets, 1000 if rows == 1 else 100)
+            rec = {"us_per_launch": round(us, 3), "GBps": round(linear_bytes(rows, K_DIM, N_DIM) / us / 1e3, 1),
+                   "tflops": round(2 * rows * K_DIM * N_DIM / us / 1e6, 1)}
+            if rows == 1:
+                rec["frac_of_8TBps"] = round(linear_bytes(rows, K_DIM, N_DIM) / us / 1e3 / HBM_PEAK_GBPS, 4)
+                y_op = ops.awq_gemm(xo, cols[0].qweight, cols[0].scales, cols[0].qzeros, 1)
+                rec["bit_identical_to_awq_gemm_repacked"] = bool(torch.equal(
+                    y_op, ops.awq_gemm_repacked(xo, cols[0].awq_packed, K_DIM, N_DIM, GROUP)))
+            else:
+                rec["frac_of_2p5PF"] = round(2 * rows * K_DIM * N_DIM / us / 1e6 / MFMA_PEAK_TFLOPS, 4)
+            op_rec[f"m{rows}"] = rec
+        op_rec["note"] = ("torch.ops.sgl_kernel.awq_gemm(x, qweight, scales, qzeros, 1) on the AutoAWQ tensors; with the cache on, the op keeps "
+                          "one MFMA-fragment-major copy per weight (made on the first eager call, validated by tensor versions and storage "
+                          "weak references) and runs the same kernels as awq_gemm_repacked; SGLANG_AWQ_AMD_OP_CACHE=0 gives the "
+                          "checkpoint-layout split-K kernel (13 us at M = 1)")
+        ops.awq_gemm_cache_clear()
 
     # context only (not the metric): the same decode kernel on a 70B-class matrix, where the fixed per-launch costs
     # (kernel boundary, time to first load, reduction) amortise — what fraction of peak the kernel itself reaches
     big = None
-    if rank == 0 and world == 1 and M == 1:
+    if "large" in sections and M == 1:
         BK, BN, nb = 8192, 28672, 5                      # 5 x 122 MB of packed weight: more than 2 x the Infinity Cache
         gen = torch.Generator(device=dev); gen.manual_seed(99)
         packs = []
@@ -273,76 +468,80 @@ def main():
             packs.append(ops.awq_repack(bqw, bsc, bqz))
             del bqw, bqz, bsc
         xb = torch.randn(1, BK, device=dev, generator=gen).half()
-
-        def big_pass():
-            for pk in packs:
-                ops.awq_gemm_repacked(xb, pk, BK, BN, GROUP)
-        big_pass()
-        torch.cuda.synchronize()
-        g_big = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_big):
-            big_pass()
-        for _ in range(3):
-            g_big.replay()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(40):
-            g_big.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        big_us = e0.elapsed_time(e1) * 1e3 / (40 * nb)
-        big_bytes = BK * BN // 2 + (BK // GROUP) * BN // 2 + (BK // GROUP) * BN * 2 + BK * 2 + BN * 2
+        big_us = graph_time(lambda: [ops.awq_gemm_repacked(xb, pk, BK, BN, GROUP) for pk in packs], nb, 200)
+        big_bytes = linear_bytes(1, BK, BN)
         big = {"shape": f"M=1 K={BK} N={BN} g={GROUP}", "us_per_launch": round(big_us, 2), "GBps": round(big_bytes / big_us / 1e3, 1),
                "frac_of_8TBps": round(big_bytes / big_us / 1e3 / HBM_PEAK_GBPS, 4)}
         del packs
+
+    # ---- Llama-2-7B-AWQ decode, TP = 1 (BASELINE configs[3]) ----------------------------------------------------
+    decode = None
+    if "decode" in sections:
+        del layer_sets, graphs
+        torch.cuda.empty_cache()
+        import bench_decode
+
+        try:
+            recs = bench_decode.measure("7b", [1, 32], steps=48, context=1024, dev=dev)
+            decode = {"method": "median over 48 single-step latencies, each bracketed by torch.cuda.synchronize (bench_one_batch.py:497-623); "
+                                "1024 positions already in the KV cache; greedy; synthetic weights; whole step replayed from one HIP graph",
+                      "weight_GB_per_step": recs[0]["weight_GB_per_step"]}
+            for r in recs:
+                decode[f"bs{r['batch']}"] = {k: r[k] for k in ("value", "unit", "median_step_ms", "device_step_ms", "tok_per_s_device", "hbm_GBps_device")}
+        except Exception as e:      # the headline must not be lost to the harness
+            decode = {"error": repr(e)}
 
     if rank != 0:
         if world > 1:
             dist.barrier()
         return
 
-    launches_per_step = 2
-    per_launch = ev / (args.steps * launches_per_step) if world == 1 else None
-    bytes_step = launches_per_step * algorithmic_bytes(M)
-    value = world * bytes_step * args.steps / wall / 1e9
-    flops_step = launches_per_step * 2 * M * K_DIM * N_DIM
+    launches_per_step = len(plan)
+    per_launch = ev / (args.steps * launches_per_step) if (world == 1 and ev == ev) else None
+    value = world * bytes_step_rank * args.steps / wall / 1e9
+    headline_shape = args.shapes == "baseline"
     out = {
         "metric": "AWQ int4 GEMM GB/s (algorithmic bytes: packed weight + x + y) at the decode shape" if M <= 64 else
                   "AWQ int4 GEMM at the prefill shape (see roofline for TFLOP/s)",
         "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(wall / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(wall / args.steps * 1e3, 6), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"awq_gemm M={M} K={K_DIM} N={N_DIM} g={GROUP} fp16 (BASELINE configs[{1 if M <= 64 else 2}]); step = column-parallel + "
-                               f"row-parallel AWQ linear per rank" + (" + RCCL all-reduce [M,11008] fp16" if world > 1 else ""),
-                   "weight_sets": sets, "graph_replay": use_graph, "parallelism": f"tp{world}",
-                   "tflops": round(world * flops_step * args.steps / wall / 1e12, 3),
+        "config": {"workload": (f"awq_gemm M={M} K={K_DIM} N={N_DIM} g={GROUP} fp16 (BASELINE configs[{1 if M <= 64 else 2}]); step = column-parallel + "
+                                f"row-parallel AWQ linear per rank" if headline_shape else
+                                f"Llama-2-70B TP=8 per-rank AWQ linears at M={M} (BASELINE configs[4]): qkv 8192->1280, o 1024->8192, gate_up 8192->7168, down 3584->8192")
+                               + (f" + RCCL all-reduce {ar_payloads} B" if world > 1 else ""),
+                   "per_rank_linears": [f"{kind} {K}x{N}" for kind, K, N in rank_shapes],
+                   "weight_sets": sets, "graph_replay": use_graph, "graph_capture_error": capture_error, "parallelism": f"tp{world}",
+                   "tflops": round(world * flops_step_rank * args.steps / wall / 1e12, 3),
                    "weight_layout": "MFMA-fragment-major copy made once at load (awq_repack); checkpoint tensors kept",
-                   "same_kernel_large_matrix": big,
-                   "awq_gemm_op_checkpoint_layout": None if op_us is None else {
-                       "us_per_launch": round(op_us, 3), "GBps": round(algorithmic_bytes(M) / op_us / 1e3, 1),
-                       "frac_of_8TBps": round(algorithmic_bytes(M) / op_us / 1e3 / HBM_PEAK_GBPS, 4),
-                       "pmc_traffic_bytes": PMC_TRAFFIC_BYTES_M1_CHECKPOINT_LAYOUT if M == 1 else None,
-                       "tflops": round(2 * M * K_DIM * N_DIM / op_us / 1e6, 1),
-                       "note": "split-K kernel on the AutoAWQ layout" if M <= 16 else
-                               "prefill-sized call: the op repacks into workspace on the fly, then the fragment-major kernel"}},
+                   "same_kernel_large_matrix": big},
     }
-    if world == 1:
-        ach = algorithmic_bytes(M) / per_launch / 1e9
-        bound = "hbm" if M <= 64 else "mfma"
-        if bound == "hbm":
+    if world > 1:
+        out["config"]["collective"] = {"backend": test_backend or "nccl (RCCL)", "all_reduce_bytes": ar_payloads, "in_graph": use_graph,
+                                       "rccl": rccl_summary(rccl_log + ".*.log") if rccl_log else None}
+    if per_launch is not None:
+        if M <= 64:
+            ach = bytes_step_rank / launches_per_step / per_launch / 1e9
+            traffic, traffic_files = pmc_traffic("gemv_rp2_kernel") if (headline_shape and M == 1) else (None, [])
             out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBPS, 4),
-                               "traffic": PMC_TRAFFIC_BYTES_M1 if M == 1 else None,
-                               "traffic_note": "bytes per launch, rocprofv3 PMC passes committed under profiles/ (not collected live)",
-                               "kernel": "gemv_repacked_kernel", "us_per_launch": round(per_launch * 1e6, 3),
-                               "cache_hot_GBps": round(algorithmic_bytes(M) / (hot / launches_per_step) / 1e9, 1) if hot else None}
+                               "frac": round(ach / HBM_PEAK_GBPS, 4), "frac_of_measured_copy": round(ach / HBM_COPY_GBPS, 4),
+                               "traffic": traffic,
+                               "traffic_note": "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE read from the committed rocprofv3 PMC passes "
+                                               f"{traffic_files} (separate --pmc runs, not collected live)",
+                               "kernel": "gemv_rp2_kernel" if headline_shape else "gemv_rp2_kernel / gemv_repacked_kernel (per shape)",
+                               "us_per_launch": round(per_launch * 1e6, 3),
+                               "timing": f"HIP events around the {args.steps} timed steps ({args.steps * launches_per_step} launches, "
+                                         f"{'one graph replay' if use_graph and args.steps <= MAX_GRAPH_STEPS else 'graph replays' if use_graph else 'eager'}); kernel boundaries are inside the interval",
+                               "cache_hot_GBps": round(bytes_step_rank / launches_per_step / hot / 1e3, 1) if hot else None}
         else:
-            tf = 2 * M * K_DIM * N_DIM / per_launch / 1e12
+            tf = flops_step_rank / launches_per_step / per_launch / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None, "us_per_launch": round(per_launch * 1e6, 3)}
-        if args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, M)
+    for name, rec in (("prefill", prefill), ("dequantize", dequant), ("awq_gemm_op", op_rec), ("decode_7b_tp1", decode)):
+        if rec is not None:
+            out[name] = rec
+    if world == 1 and args.cpu_seconds > 0 and not cpu_rehearsal:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, M)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

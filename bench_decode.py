@@ -26,6 +26,73 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def measure(model_name: str, batches, steps: int = 64, context: int = 1024, dev=None, verbose: bool = False):
+    """Decode tok/s of a synthetic Llama-AWQ model per batch size: median over `steps` single-step latencies, each bracketed by
+    torch.cuda.synchronize (the method of the reference's bench_one_batch.py:497-623), plus the device-only time of the same
+    step (16 graph replays back to back between HIP events).  Returns one dict per batch size."""
+    import torch
+
+    from sglang_awq_amd.awq import AWQConfig
+    from sglang_awq_amd.distributed import get_tensor_model_parallel_world_size
+    from sglang_awq_amd.llama import GraphedDecoder, LlamaConfig, LlamaForCausalLM
+
+    world = get_tensor_model_parallel_world_size()
+    if dev is None:
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    if model_name == "7b":
+        cfg = LlamaConfig.llama2_7b()
+    elif model_name == "70b":
+        cfg = LlamaConfig.llama2_70b()
+    else:
+        cfg = LlamaConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=4, num_attention_heads=8, num_key_value_heads=8,
+                          vocab_size=2048)
+    max_seq = context + steps + 32
+    with torch.device(dev):
+        model = LlamaForCausalLM(cfg, AWQConfig(4, 128, True), max_batch=max(batches), max_seq=max_seq)
+    model.init_synthetic_(0)
+    torch.cuda.synchronize()
+
+    # weight bytes one decode step must stream (packed AWQ linears + fp16 lm_head): the HBM floor
+    lin_bytes = sum(l.qweight.numel() * 4 + l.qzeros.numel() * 4 + l.scales.numel() * 2
+                    for layer in model.layers for l in (layer.qkv_proj, layer.o_proj, layer.gate_up_proj, layer.down_proj))
+    head_bytes = model.lm_head.numel() * 2
+    name = {"7b": "Llama-2-7B-AWQ", "70b": "Llama-2-70B-AWQ", "tiny": "tiny-llama"}[model_name]
+    results = []
+    for B in batches:
+        dec = GraphedDecoder(model, B, start_pos=context).capture(warmup=2)
+        dec.run(3)
+        lat = []
+        for _ in range(steps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dec.run(1)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+        med = statistics.median(lat)
+        # device-only time of the same step: K replays back to back between HIP events
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dec.reset()
+        e0.record()
+        for _ in range(16):
+            dec.run(1)
+        e1.record()
+        torch.cuda.synchronize()
+        dev_ms = e0.elapsed_time(e1) / 16
+        r = {"metric": f"{name} decode tok/s TP={world}", "batch": B,
+             "value": round(B / med, 1), "unit": "tok/s", "median_step_ms": round(med * 1e3, 4), "device_step_ms": round(dev_ms, 4),
+             "tok_per_s_device": round(B / (dev_ms * 1e-3), 1), "context": context, "steps": steps,
+             "weight_GB_per_step": round((lin_bytes + head_bytes) / 1e9, 3),
+             "hbm_GBps_device": round((lin_bytes + head_bytes) / (dev_ms * 1e-3) / 1e9, 1), "data": "synthetic", "dtype": "f16",
+             "graph_replay": dec.graph is not None, "graph_capture_error": dec.capture_error}
+        results.append(r)
+        if verbose:
+            print(json.dumps(r), flush=True)
+        del dec
+    del model
+    torch.cuda.empty_cache()
+    return results
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="7b", choices=["7b", "70b", "tiny"])
@@ -38,65 +105,18 @@ def main():
 
     import torch
 
-    from sglang_awq_amd.awq import AWQConfig
-    from sglang_awq_amd.llama import GraphedDecoder, LlamaConfig, LlamaForCausalLM
-
     from sglang_awq_amd.distributed import init_tensor_parallel
+    from sglang_awq_amd.llama import LlamaConfig
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
     init_tensor_parallel(backend="nccl", device=dev) if world > 1 else init_tensor_parallel()
-    if args.model == "7b":
-        cfg = LlamaConfig.llama2_7b()
-    elif args.model == "70b":
-        cfg = LlamaConfig.llama2_70b()
-    else:
-        cfg = LlamaConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=4, num_attention_heads=8, num_key_value_heads=8,
-                          vocab_size=2048)
     batches = [int(b) for b in args.batches.split(",")]
-    max_seq = args.context + args.steps + 16
-    with torch.device(dev):
-        model = LlamaForCausalLM(cfg, AWQConfig(4, 128, True), max_batch=max(batches), max_seq=max_seq)
-    model.init_synthetic_(0)
-    torch.cuda.synchronize()
-
-    # weight bytes one decode step must stream (packed AWQ linears + fp16 lm_head): the HBM floor
-    lin_bytes = sum(l.qweight.numel() * 4 + l.qzeros.numel() * 4 + l.scales.numel() * 2
-                    for layer in model.layers for l in (layer.qkv_proj, layer.o_proj, layer.gate_up_proj, layer.down_proj))
-    head_bytes = model.lm_head.numel() * 2
-    results = []
-    for B in batches:
-        dec = GraphedDecoder(model, B, start_pos=args.context).capture(warmup=2)
-        dec.run(3)
-        lat = []
-        for _ in range(args.steps):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            dec.run(1)
-            torch.cuda.synchronize()
-            lat.append(time.perf_counter() - t0)
-        med = statistics.median(lat)
-        # device-only time of the same step: K replays back to back between HIP events
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        dec.pos.fill_(args.context)
-        e0.record()
-        for _ in range(16):
-            dec.run(1)
-        e1.record()
-        torch.cuda.synchronize()
-        dev_ms = e0.elapsed_time(e1) / 16
-        name = {"7b": "Llama-2-7B-AWQ", "70b": "Llama-2-70B-AWQ", "tiny": "tiny-llama"}[args.model]
-        r = {"metric": f"{name} decode tok/s TP={world}", "batch": B,
-             "value": round(B / med, 1), "unit": "tok/s", "median_step_ms": round(med * 1e3, 4), "device_step_ms": round(dev_ms, 4),
-             "tok_per_s_device": round(B / (dev_ms * 1e-3), 1), "context": args.context, "steps": args.steps,
-             "weight_GB_per_step": round((lin_bytes + head_bytes) / 1e9, 3),
-             "hbm_GBps_device": round((lin_bytes + head_bytes) / (dev_ms * 1e-3) / 1e9, 1), "data": "synthetic", "dtype": "f16"}
-        results.append(r)
-        if rank == 0:
-            print(json.dumps(r), flush=True)
-        del dec
+    results = measure(args.model, batches, args.steps, args.context, dev, verbose=(rank == 0))
+    cfg = {"7b": LlamaConfig.llama2_7b, "70b": LlamaConfig.llama2_70b}.get(args.model, lambda: LlamaConfig(
+        hidden_size=512, intermediate_size=1024, num_hidden_layers=4, num_attention_heads=8, num_key_value_heads=8, vocab_size=2048))()
 
     cpu = None
     if args.cpu_seconds > 0 and rank == 0:

@@ -42,14 +42,16 @@ _attn_ws_retired = []
 
 
 def _attention_workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
-    """Per-device scratch of the split-S attention (tickets + partials); zero-filled once, every call leaves the tickets zero.
-    Allocate it outside graph capture (the first, uncaptured call of a shape does)."""
-    ws = _attn_ws.get(dev.index)
+    """Scratch of the split-S attention (tickets + partials) per (device, stream): the tickets are live during a call, so two
+    streams of one device never share them.  Zero-filled once, every call leaves the tickets zero.  Allocate it outside graph
+    capture (the first, uncaptured call of a shape does)."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _attn_ws.get(key)
     if ws is None or ws.numel() < nbytes:
         if ws is not None:
             _attn_ws_retired.append(ws)          # a captured graph may still point at it
         ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
-        _attn_ws[dev.index] = ws
+        _attn_ws[key] = ws
     return ws
 
 
@@ -115,6 +117,9 @@ def gemv_repacked_fused(packed: torch.Tensor, K: int, N: int, group_size: int, x
     assert src is not None and src.dtype == torch.float16 and src.dim() == 2 and src.is_contiguous() and src.shape[1] == K
     M = src.shape[0]
     dev = src.device
+    from .ops import check_packed
+
+    check_packed(packed, K, N, group_size, dev)
     y = torch.empty((M, N // 2 if silu_mul else N), dtype=torch.float16, device=dev)
     h_out = None
     if norm is not None:

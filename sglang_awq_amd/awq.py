@@ -137,24 +137,43 @@ class AWQLinearMethod(LinearMethodBase):
         # awq_marlin_repack step, awq.py AWQMarlinLinearMethod.process_weights_after_loading).  The original
         # tensors stay: awq_dequantize and the prefill kernel consume the checkpoint layout.
         layer.awq_packed = None
-        if self.repack and self.apply_mode == "fused" and layer.qweight.is_cuda and layer.scales.dtype == torch.float16:
+        if layer.qweight.is_cuda:
             from . import ops
 
-            layer.awq_packed = ops.awq_repack(layer.qweight.data, layer.scales.data, layer.qzeros.data)
+            ops.awq_gemm_cache_clear()           # (re)loaded weights: copies the drop-in op made of the old values are stale
+            if self.repack and self.apply_mode == "fused" and layer.scales.dtype == torch.float16:
+                layer.awq_packed = ops.awq_repack(layer.qweight.data, layer.scales.data, layer.qzeros.data)
+                # SGLANG_AWQ_AMD_KEEP_CHECKPOINT=0: a fused-only deployment never reads the checkpoint tensors again (every batch
+                # size runs on the repacked copy); releasing them halves the weight memory (70B at TP = 1: 35 GB).  The
+                # parameters stay registered with their shapes' metadata (`awq_shape`) but empty storage, so
+                # `sgl_kernel.awq_dequantize(layer.qweight, ...)` on such a layer raises instead of reading freed memory.
+                if layer.awq_packed is not None and os.environ.get("SGLANG_AWQ_AMD_KEEP_CHECKPOINT", "1") == "0":
+                    K, C = layer.qweight.shape
+                    layer.awq_shape = (K, C * self.quant_config.pack_factor, K // layer.scales.shape[0])
+                    for name in ("qweight", "qzeros", "scales"):
+                        t = getattr(layer, name)
+                        setattr(layer, name, torch.nn.Parameter(torch.empty(0, dtype=t.dtype, device=t.device), requires_grad=False))
 
     def apply(self, layer: torch.nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         from . import ops
 
         qweight, scales, qzeros = layer.qweight, layer.scales, layer.qzeros
-        out_shape = x.shape[:-1] + (qweight.shape[-1] * self.quant_config.pack_factor,)
-        reshaped_x = x.reshape(-1, x.shape[-1])
         packed = getattr(layer, "awq_packed", None)
+        released = getattr(layer, "awq_shape", None)         # checkpoint tensors released (SGLANG_AWQ_AMD_KEEP_CHECKPOINT=0)
+        if released is not None:
+            K, N, g = released
+        else:
+            K, N, g = qweight.shape[0], qweight.shape[-1] * self.quant_config.pack_factor, qweight.shape[0] // max(scales.shape[0], 1)
+        out_shape = x.shape[:-1] + (N,)
+        reshaped_x = x.reshape(-1, x.shape[-1])
         if packed is not None and reshaped_x.shape[0] <= self.REPACKED_MAX_M and reshaped_x.shape[0] > 0:
-            K = qweight.shape[0]
-            try:
-                out = ops.awq_gemm_repacked(reshaped_x, packed, K, out_shape[-1], K // scales.shape[0], bias)
-            except ops.AwqHipError:     # e.g. M = 32 on a very wide strip: reduction scratch over the LDS guard
-                out = ops.awq_linear(reshaped_x, qweight, scales, qzeros, bias)
+            if released is not None:
+                out = ops.awq_gemm_repacked(reshaped_x, packed, K, N, g, bias)     # no checkpoint-layout route left: errors propagate
+            else:
+                try:
+                    out = ops.awq_gemm_repacked(reshaped_x, packed, K, N, g, bias)
+                except ops.AwqHipError:     # e.g. M = 32 on a very wide strip: reduction scratch over the LDS guard
+                    out = ops.awq_linear(reshaped_x, qweight, scales, qzeros, bias)
         elif self.apply_mode == "fused":
             out = ops.awq_linear(reshaped_x, qweight, scales, qzeros, bias)
         else:

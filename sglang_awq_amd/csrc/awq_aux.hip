@@ -92,7 +92,9 @@ __global__ void rope_kv_kernel(half_t* __restrict__ qkv, const int64_t* __restri
                                const float* __restrict__ sin_t, half_t* __restrict__ kc, half_t* __restrict__ vc, int Hq, int Hkv, int D,
                                int S) {
   const int b = blockIdx.y, head = blockIdx.x, t = threadIdx.x, half = D / 2;
-  const int64_t p = pos[b];
+  const int64_t p_raw = pos[b];
+  const bool in_range = p_raw >= 0 && p_raw < S;                    // a position outside the cache: rotate with the clamped angle, store nothing
+  const int64_t p = p_raw < 0 ? 0 : (p_raw < S ? p_raw : S - 1);
   half_t* row = qkv + (size_t)b * (Hq + 2 * Hkv) * D + (size_t)head * D;
   if (head < Hq + Hkv) {
     const float c = cos_t[p * half + t], s = sin_t[p * half + t];
@@ -100,12 +102,12 @@ __global__ void rope_kv_kernel(half_t* __restrict__ qkv, const int64_t* __restri
     const half_t o1 = (half_t)(x1 * c - x2 * s), o2 = (half_t)(x2 * c + x1 * s);
     row[t] = o1;
     row[t + half] = o2;
-    if (head >= Hq) {
+    if (head >= Hq && in_range) {
       half_t* dst = kc + (((size_t)b * Hkv + (head - Hq)) * S + p) * D;
       dst[t] = o1;
       dst[t + half] = o2;
     }
-  } else {
+  } else if (in_range) {
     half_t* dst = vc + (((size_t)b * Hkv + (head - Hq - Hkv)) * S + p) * D;
     dst[t] = row[t];
     dst[t + half] = row[t + half];
@@ -161,7 +163,10 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const half_t* __r
     vv[u] = *(const half8v*)(vbase + (size_t)jc * D + lp * 8);
   }
 
-  const int p = (int)pos[b];                                        // cached positions 0 .. p-1, the new token is p
+  const int64_t p_raw = pos[b];                                     // cached positions 0 .. p-1, the new token is p
+  // the host (GraphedDecoder) refuses to step past the cache; should a caller get here with p >= S anyway, clamp: the last
+  // slot is overwritten and attended to, nothing outside the cache or the rotary tables is touched
+  const int p = (int)(p_raw < 0 ? 0 : (p_raw < S ? p_raw : S - 1));
   const bool has_new = (p / BLK) % ns == sp;                         // the split whose block holds the new token stores it
   const half_t* row = qkv + (size_t)b * (Hq + 2 * Hkv) * D;
   if (t < HALF) {                                                    // q: rotate, round to fp16 as the unfused path does, pre-scale

@@ -33,7 +33,19 @@ static int repacked_dispatch(const GemmArgs& a, const void* packed) {
   // wide tiles are few (narrow matrices, up to 512 rows) 128 x 64 tiles with the K split inside the workgroup fill the
   // chip better (11008 x 4096 at M = 256: 142 -> 90 us); beyond that the hand-pipelined wide tiles.
   static const int env_mid = getenv("AWQ_MID") ? atoi(getenv("AWQ_MID")) : 1;      // A/B knob: 0 = never the 128 x 64 tiles
-  if (M <= 32) return launch_gemv_repacked(a, packed);
+  if (M <= 32) {
+    const int rc = launch_gemv_repacked(a, packed);
+    if (rc != AWQ_ERR_BAD_VARIANT || M <= 16) return rc;
+    // 17..32 rows on a strip whose two-row-tile reduction scratch does not fit the CU's LDS: two passes of <= 16 rows
+    GemmArgs c = a;
+    c.M = 16;
+    const int rc1 = launch_gemv_repacked(c, packed);
+    if (rc1) return rc1;
+    c.M = (int)M - 16;
+    c.x = (const char*)a.x + (size_t)16 * a.ldx * 2;
+    c.y = (char*)a.y + (size_t)16 * a.N * 2;
+    return launch_gemv_repacked(c, packed);
+  }
   const bool aligned = a.ldx % 8 == 0 && (((uintptr_t)a.x) & 15) == 0;
   const int64_t wide_tiles = ((M + 127) / 128) * ((a.N + 255) / 256);
   if (env_mid != 0 && aligned && M > 96 && wide_tiles <= 64) return launch_gemm_repacked_ksplit(a, packed);
@@ -182,6 +194,8 @@ int awq_gemm_repacked(const void* x, int64_t ldx, const void* packed, const void
   if (M == 0) return AWQ_OK;
   if (!x || !y) return AWQ_ERR_NULL_POINTER;
   if ((((uintptr_t)packed) & 15) || (((uintptr_t)y) & 1)) return AWQ_ERR_MISALIGNED;
+  // every kernel behind this entry indexes `packed` from (K, N, group_size) alone: refuse shapes the layout does not exist for
+  if (!repacked_supported(K, N, group_size, dtype) || M > INT32_MAX / 2) return AWQ_ERR_BAD_VARIANT;
   GemmArgs a;
   a.x = x; a.ldx = ldx; a.qweight = nullptr; a.scales = nullptr; a.qzeros = nullptr; a.bias = bias; a.y = y;
   a.workspace = nullptr; a.workspace_bytes = 0;

@@ -59,4 +59,16 @@ int launch_gemm_repacked_tiled(const GemmArgs& a, const void* packed);   // any 
 int launch_gemm_repacked_ksplit(const GemmArgs& a, const void* packed);      // 128 x 64 tiles, K split inside the workgroup (middle M)
 int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed);   // its hand-pipelined 128 x 256 form (awq_repacked_prefill.hip)
 
+// Opt a kernel in to more than 64 KiB of dynamic LDS on the CURRENT device.  The attribute belongs to the function object of
+// a device, and the shim serves several devices from one process: remember per (kernel, device) instead of once per process.
+// Returns false when the runtime refuses (callers report AWQ_ERR_LAUNCH / fall back).
+inline bool opt_in_dynamic_lds(const void* kernel, int bytes, unsigned long long (&done)[2]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return false;
+  if (dev < 128 && (done[dev >> 6] >> (dev & 63) & 1ull)) return true;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  if (dev < 128) done[dev >> 6] |= 1ull << (dev & 63);
+  return true;
+}
+
 }  // namespace awq

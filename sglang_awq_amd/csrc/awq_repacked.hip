@@ -275,7 +275,8 @@ static void pf_launch(const GemmArgs& a, const u32x4_t* qw_r, const uint32_t* zs
   constexpr int BMt = WM * MI * 16, BNt = WN * 64;
   const int nbx = (a.N + BNt - 1) / BNt, nby = (a.M + BMt - 1) / BMt;
   const size_t lds = 2 * BMt * 256;
-  (void)hipFuncSetAttribute((const void*)gemm_repacked_tiled_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static unsigned long long opted[2] = {0ull, 0ull};
+  if (!opt_in_dynamic_lds((const void*)gemm_repacked_tiled_kernel<WM, WN>, (int)lds, opted)) return;
   hipLaunchKernelGGL((gemm_repacked_tiled_kernel<WM, WN>), dim3(nbx * nby), dim3(WM * WN * 64), lds, a.stream, (const uint16_t*)a.x, a.ldx,
                      qw_r, zs_r, a.bias, a.y, a.M, a.K, a.N, a.g, NG, nbx, nby);
 }
@@ -382,9 +383,11 @@ int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
   const int per_wave = (KB + W - 1) / W;
   const size_t lds = (size_t)W * a.M * 16 * G * sizeof(float);
   if (lds > (size_t)(two_tiles ? kRpMaxLds : 64 * 1024)) return AWQ_ERR_BAD_VARIANT;
-  if (two_tiles) rp_launch_g<8, true, 2>(G, a, packed, NG, per_wave, T, nwg, lds);
-  else if (W == 16) { if (nt) rp_launch_g<16, true, 1>(G, a, packed, NG, per_wave, T, nwg, lds); else rp_launch_g<16, false, 1>(G, a, packed, NG, per_wave, T, nwg, lds); }
-  else { if (nt) rp_launch_g<8, true, 1>(G, a, packed, NG, per_wave, T, nwg, lds); else rp_launch_g<8, false, 1>(G, a, packed, NG, per_wave, T, nwg, lds); }
+  bool launched;
+  if (two_tiles) launched = rp_launch_g<8, true, 2>(G, a, packed, NG, per_wave, T, nwg, lds);
+  else if (W == 16) launched = nt ? rp_launch_g<16, true, 1>(G, a, packed, NG, per_wave, T, nwg, lds) : rp_launch_g<16, false, 1>(G, a, packed, NG, per_wave, T, nwg, lds);
+  else launched = nt ? rp_launch_g<8, true, 1>(G, a, packed, NG, per_wave, T, nwg, lds) : rp_launch_g<8, false, 1>(G, a, packed, NG, per_wave, T, nwg, lds);
+  if (!launched) return AWQ_ERR_BAD_VARIANT;             // no such instantiation (e.g. a combination forced through the AWQ_RP_* knobs): nothing ran
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 

@@ -12,8 +12,8 @@
 namespace awq {
 
 template <int PRO, int EPI>
-static void fused_go(int G, const GemmArgs& a, const void* packed, int NG, int per_wave, int T, int nwg, size_t lds) {
-  rp_launch_g<16, true, 1, PRO, EPI>(G, a, packed, NG, per_wave, T, nwg, lds);
+static bool fused_go(int G, const GemmArgs& a, const void* packed, int NG, int per_wave, int T, int nwg, size_t lds) {
+  return rp_launch_g<16, true, 1, PRO, EPI>(G, a, packed, NG, per_wave, T, nwg, lds);
 }
 
 int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed) {
@@ -30,7 +30,7 @@ int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed) {
     const int T2 = (pw == 4 && rp_fits(8, 2, G2, 4)) ? 4 : 0;
     const size_t lds2 = (size_t)8 * a.M * 16 * G2 * sizeof(float);
     if (lds2 > (size_t)kRpMaxLds) return AWQ_ERR_BAD_VARIANT;
-    rp_launch_g<8, true, 2, 0, 1>(G2, a, packed, NG2, pw, T2, (NG2 + G2 - 1) / G2, lds2);
+    if (!rp_launch_g<8, true, 2, 0, 1>(G2, a, packed, NG2, pw, T2, (NG2 + G2 - 1) / G2, lds2)) return AWQ_ERR_BAD_VARIANT;
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
   }
   if (!norm && (((uintptr_t)a.x) & 15)) return AWQ_ERR_BAD_VARIANT;
@@ -44,7 +44,7 @@ int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed) {
     // launcher does, with the SiLU-mul epilogue (a strip holds two (gate, up) pairs)
     const int pw = (KB + 7) / 8;
     const size_t lds_r = (size_t)8 * a.M * 16 * 4 * sizeof(float);
-    rp_launch<4, 8, true, 1, 0, 1>(a, packed, NG, pw, 0, (NG + 3) / 4, lds_r);
+    if (!rp_launch<4, 8, true, 1, 0, 1>(a, packed, NG, pw, 0, (NG + 3) / 4, lds_r)) return AWQ_ERR_BAD_VARIANT;
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
   }
   if (G > kRpMaxG || G > NG) return AWQ_ERR_BAD_VARIANT;
@@ -65,16 +65,18 @@ int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed) {
   if (!rp_fits_fused(G, T, PRO, a.silu_mul)) return AWQ_ERR_BAD_VARIANT;
   if (norm) lds += (size_t)W * a.M * (T * 128 + 8) * 2 + (size_t)W * PRO * 4 * sizeof(float);
   if (lds > (size_t)kRpMaxLds) return AWQ_ERR_BAD_VARIANT;
+  bool launched;
   if (a.silu_mul) {
-    if (PRO == 0) fused_go<0, 1>(G, a, packed, NG, T, T, nwg, lds);
-    else if (PRO == 1) fused_go<1, 1>(G, a, packed, NG, T, T, nwg, lds);
-    else if (PRO == 2) fused_go<2, 1>(G, a, packed, NG, T, T, nwg, lds);
-    else fused_go<4, 1>(G, a, packed, NG, T, T, nwg, lds);
+    if (PRO == 0) launched = fused_go<0, 1>(G, a, packed, NG, T, T, nwg, lds);
+    else if (PRO == 1) launched = fused_go<1, 1>(G, a, packed, NG, T, T, nwg, lds);
+    else if (PRO == 2) launched = fused_go<2, 1>(G, a, packed, NG, T, T, nwg, lds);
+    else launched = fused_go<4, 1>(G, a, packed, NG, T, T, nwg, lds);
   } else {
-    if (PRO == 1) fused_go<1, 0>(G, a, packed, NG, T, T, nwg, lds);
-    else if (PRO == 2) fused_go<2, 0>(G, a, packed, NG, T, T, nwg, lds);
-    else fused_go<4, 0>(G, a, packed, NG, T, T, nwg, lds);
+    if (PRO == 1) launched = fused_go<1, 0>(G, a, packed, NG, T, T, nwg, lds);
+    else if (PRO == 2) launched = fused_go<2, 0>(G, a, packed, NG, T, T, nwg, lds);
+    else launched = fused_go<4, 0>(G, a, packed, NG, T, T, nwg, lds);
   }
+  if (!launched) return AWQ_ERR_BAD_VARIANT;
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 

@@ -509,7 +509,8 @@ static bool rp2_launch_t(const GemmArgs& a, const void* packed, int NG, int chun
 #define RP2_GO(CHS, DEP, ONE)                                                                                                      \
     do {                                                                                                                           \
       auto kern = gemv_rp2_kernel<G, T, CHS, DEP, EPI, ONE>;                                                                       \
-      if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kRpMaxLds) != hipSuccess) return false; \
+      static unsigned long long opted[2] = {0ull, 0ull};                                                                           \
+      if (lds > 64 * 1024 && !opt_in_dynamic_lds((const void*)kern, kRpMaxLds, opted)) return false;                                \
       hipLaunchKernelGGL(kern, dim3(nwg), dim3(1024), lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r, a.bias, a.y, a.M, a.K, \
                          a.N, a.K / a.g, gmul, gshift, NG);                                                                        \
       return true;                                                                                                                 \
@@ -595,8 +596,9 @@ constexpr bool rp_fits_fused(int G, int T, int PRO, int EPI) {
 // x staged through wave-private LDS (PRO < 0), 16 waves: T k-blocks of 5 G registers each (tools/rp_resources.py)
 constexpr bool rp_fits_xl(int G, int T) { return T >= 1 && T <= 8 && G * T <= 16; }
 
+// returns false when no instantiation exists for (G, T, W, MT, PRO, EPI) or the LDS opt-in failed: nothing was enqueued
 template <int G, int W, bool NT, int MT, int PRO, int EPI>
-static void rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wave, int T, int nwg, size_t lds) {
+static bool rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wave, int T, int nwg, size_t lds) {
   const u32x4_t* qw_r = (const u32x4_t*)packed;
   const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
   const RpFuse fz = {(const half_t*)a.norm_h, (const half_t*)a.norm_delta, (const half_t*)a.norm_w, (half_t*)a.norm_h_out, a.norm_eps};
@@ -607,12 +609,13 @@ static void rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wav
                                        : (W == 16 ? (NT && MT == 1 && rp_fits_fused(G, TT, PRO, EPI))                                            \
                                                  : (W == 8 && NT && MT == 1 && PRO == 0 && EPI == 1 && TT == 0 && G == 4))) { /* SiLU epilogue in rounds mode */ \
     auto kern = gemv_repacked_kernel<G, TT, W, NT, MT, PRO, EPI>;                                                                       \
-    if (lds > 64 * 1024) {                       /* one workgroup per CU: opt in to more of its 160 KiB of LDS, once */                  \
-      static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kRpMaxLds);     \
-      (void)once;                                                                                                                       \
+    if (lds > 64 * 1024) {                       /* one workgroup per CU: opt in to more of its 160 KiB of LDS, once per device */       \
+      static unsigned long long opted[2] = {0ull, 0ull};                                                                                \
+      if (!opt_in_dynamic_lds((const void*)kern, kRpMaxLds, opted)) return false;                                                        \
     }                                                                                                                                   \
     hipLaunchKernelGGL(kern, grid, block, lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r, a.bias, a.y, a.M, a.K, a.N, a.g, NG,   \
                        per_wave, g_rp_stamp_buffer, fz);                                                                                \
+    return true;                                                                                                                        \
   }
   switch (T) {
     case 1: RP_GO(1); break;
@@ -626,19 +629,20 @@ static void rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wav
     default: RP_GO(0); break;
   }
 #undef RP_GO
+  return false;
 }
 
 template <int W, bool NT, int MT, int PRO = 0, int EPI = 0>
-static void rp_launch_g(int G, const GemmArgs& a, const void* packed, int NG, int per_wave, int T, int nwg, size_t lds) {
+static bool rp_launch_g(int G, const GemmArgs& a, const void* packed, int NG, int per_wave, int T, int nwg, size_t lds) {
   switch (G) {
-    case 1: rp_launch<1, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds); break;
-    case 2: rp_launch<2, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds); break;
-    case 3: rp_launch<3, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds); break;
-    case 4: rp_launch<4, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds); break;
-    case 5: rp_launch<5, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds); break;
-    case 6: rp_launch<6, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds); break;
-    case 7: rp_launch<7, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds); break;
-    default: rp_launch<8, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds); break;
+    case 1: return rp_launch<1, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds);
+    case 2: return rp_launch<2, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds);
+    case 3: return rp_launch<3, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds);
+    case 4: return rp_launch<4, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds);
+    case 5: return rp_launch<5, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds);
+    case 6: return rp_launch<6, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds);
+    case 7: return rp_launch<7, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds);
+    default: return rp_launch<8, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds);
   }
 }
 

@@ -222,8 +222,8 @@ int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed) {
   const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
   const int nbx = (a.N + kPfBN - 1) / kPfBN, nby = (a.M + kPfBM - 1) / kPfBM;
   const size_t lds = 2 * kPfBM * 256;
-  static const hipError_t once = hipFuncSetAttribute((const void*)gemm_repacked_pipelined_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)once;
+  static unsigned long long opted[2] = {0ull, 0ull};
+  if (!opt_in_dynamic_lds((const void*)gemm_repacked_pipelined_kernel, (int)lds, opted)) return AWQ_ERR_LAUNCH;
   hipLaunchKernelGGL(gemm_repacked_pipelined_kernel, dim3(nbx * nby), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r,
                      a.bias, a.y, a.M, a.K, a.N, a.g, NG, nbx, nby);
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
@@ -412,13 +412,14 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_ksplit_kernel(con
 }
 
 int launch_gemm_repacked_ksplit(const GemmArgs& a, const void* packed) {
+  if (!repacked_supported(a.K, a.N, a.g, a.dtype) || a.M < 1 || a.ldx % 8 || (((uintptr_t)a.x) & 15)) return AWQ_ERR_BAD_VARIANT;
   const int NG = rp_groups(a.N);
   const uint32_t* qw_r = (const uint32_t*)packed;
   const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
   const int nbx = (a.N + 63) / 64, nby = (a.M + kPfBM - 1) / kPfBM;
   const size_t lds = 4 * 8 * 4 * 4 * 64 * sizeof(float);                  // 128 KiB: four partial tiles (covers the 64 KiB of x buffers)
-  static const hipError_t once = hipFuncSetAttribute((const void*)gemm_repacked_ksplit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)once;
+  static unsigned long long opted[2] = {0ull, 0ull};
+  if (!opt_in_dynamic_lds((const void*)gemm_repacked_ksplit_kernel, (int)lds, opted)) return AWQ_ERR_LAUNCH;
   hipLaunchKernelGGL(gemm_repacked_ksplit_kernel, dim3(nbx * nby), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r,
                      a.bias, a.y, a.M, a.K, a.N, a.g, NG, nbx, nby);
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;

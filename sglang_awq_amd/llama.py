@@ -252,6 +252,10 @@ class GraphedDecoder:
         self.tokens = torch.zeros(batch, dtype=torch.int64, device=dev)
         self.pos = torch.full((batch,), start_pos, dtype=torch.int64, device=dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.capture_error: Optional[str] = None    # why run() steps eagerly, if it does
+        self.steps_taken = 0                      # host-side mirror of how far `pos` has advanced on the device
+        if start_pos >= model.max_seq:
+            raise ValueError(f"start_pos {start_pos} is outside the KV cache (max_seq {model.max_seq})")
 
     def _set_attention_splits(self):
         """Long context at small batch: one workgroup per (sequence, head) leaves most of the chip idle (batch 1, context
@@ -279,9 +283,12 @@ class GraphedDecoder:
         self._set_attention_splits()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        if self.start_pos + self.steps_taken + warmup + 1 > self.model.max_seq:
+            raise ValueError("not enough room in the KV cache for the warm-up and capture steps")
         with torch.cuda.stream(s):
             for _ in range(warmup):
                 self._step()
+        self.steps_taken += warmup + 1
         torch.cuda.current_stream().wait_stream(s)
         graph = torch.cuda.CUDAGraph()
         try:
@@ -293,12 +300,27 @@ class GraphedDecoder:
 
             print(f"GraphedDecoder: graph capture failed ({e!r}); stepping eagerly", file=sys.stderr)
             self.graph = None
+            self.capture_error = repr(e)
             torch.cuda.synchronize()
         return self
 
+    def reset(self, start_pos: Optional[int] = None) -> None:
+        """Rewind the device-side positions (the KV cache keeps whatever the earlier steps wrote)."""
+        if start_pos is not None:
+            if start_pos >= self.model.max_seq:
+                raise ValueError(f"start_pos {start_pos} is outside the KV cache (max_seq {self.model.max_seq})")
+            self.start_pos = start_pos
+        self.pos.fill_(self.start_pos)
+        self.steps_taken = 0
+
     @torch.no_grad()
     def run(self, steps: int) -> List[int]:
-        """steps decode steps (graph replays, or eager steps when capture was not possible); returns the current tokens."""
+        """steps decode steps (graph replays, or eager steps when capture was not possible); returns the current tokens.
+        Raises before the device-side position would leave the KV cache / rotary tables (the kernels index them by pos)."""
+        if self.start_pos + self.steps_taken + steps > self.model.max_seq:
+            raise ValueError(f"{steps} more steps would write past the KV cache: position {self.start_pos + self.steps_taken} of "
+                             f"{self.model.max_seq}")
+        self.steps_taken += steps
         for _ in range(steps):
             if self.graph is not None:
                 self.graph.replay()

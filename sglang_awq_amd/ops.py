@@ -20,9 +20,11 @@ caching allocator; the C side only enqueues kernels on the current stream (graph
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
+from torch.multiprocessing.reductions import StorageWeakRef
 
 from . import _lib
 from ._lib import AwqHipError  # noqa: F401  (re-exported)
@@ -79,17 +81,84 @@ class _on_device:
             self.ctx.__exit__(*exc)
 
 
-def _workspace(dev: torch.device) -> torch.Tensor:
-    """One scratch buffer per device (the reference runs one forward thread per GPU process,
-    engine.py:931).  Only the arrival counters at its head need to start at zero; every call
-    leaves them zero again, so the buffer is initialised once, outside any timed or captured
-    region when the first call is a warm-up (as it is in the reference's graph-capture flow)."""
-    ws = _workspaces.get(dev.index)
+def _workspace(dev: torch.device, stream: int) -> torch.Tensor:
+    """Scratch per (device, stream): the split-K arrival counters at its head, the fp32 slabs and (M >= 33) the target of
+    the on-the-fly re-layout are live for the duration of one call, and calls on one stream are ordered — two streams of
+    one device must never share them (alternate-stream overlap, capture on one stream while another runs).  Only the
+    counters need to start at zero; every call leaves them zero again, so a buffer is initialised once, outside any timed or
+    captured region when the first call on that stream is a warm-up (as it is in the reference's graph-capture flow)."""
+    key = (dev.index, stream)
+    ws = _workspaces.get(key)
     if ws is None:
         ws = torch.empty(_WORKSPACE_BYTES, dtype=torch.uint8, device=dev)
         ws[:4096].zero_()
-        _workspaces[dev.index] = ws
+        _workspaces[key] = ws
     return ws
+
+
+# --------------------------------------------------------------------------- repacked copies kept by the drop-in op
+# `sgl_kernel.awq_gemm` receives the checkpoint tensors on every call; the kernels that reach the HBM roofline want the
+# MFMA-fragment-major layout (awq_repack).  Serving weights are static, so the op keeps one repacked copy per weight it has
+# seen, keyed on the three tensors' storage addresses and validated on every hit by (a) the tensors' version counters
+# (in-place updates such as an RL weight sync bump `_version` -> the copy is rebuilt) and (b) weak references to the
+# storages (a freed weight whose address is reused can never alias a stale copy).  The copy is made on the first eager call
+# for a weight — never during stream capture (a capture-time miss runs the checkpoint-layout kernel) — costs
+# awq_repacked_bytes() of HBM per weight, and can be dropped with awq_gemm_cache_clear() or disabled with
+# SGLANG_AWQ_AMD_OP_CACHE=0.  Results are bit-identical to awq_gemm_repacked (same kernels).
+# Limit of (a): a write through `param.data` (e.g. `param.data.copy_(w)`, which the reference's weight loaders use) bumps the
+# version counter of the temporary `.data` alias, not of the tensor the op receives — after reloading weights in place that
+# way, call awq_gemm_cache_clear() (this package's AWQLinearMethod.process_weights_after_loading does).
+_op_cache = {}
+_OP_CACHE_ENABLED = os.environ.get("SGLANG_AWQ_AMD_OP_CACHE", "1") != "0"
+_OP_CACHE_MAX_BYTES = int(float(os.environ.get("SGLANG_AWQ_AMD_OP_CACHE_GB", "64")) * (1 << 30))
+_op_cache_bytes = 0
+
+
+def awq_gemm_cache_clear() -> None:
+    """Drop every repacked copy the awq_gemm op holds (frees the HBM once in-flight kernels have finished)."""
+    global _op_cache_bytes
+    _op_cache.clear()
+    _op_cache_bytes = 0
+
+
+def awq_gemm_cache_enable(flag: bool) -> None:
+    """Turn the op's repacked-copy cache on or off at run time (off: every call runs the checkpoint-layout kernels)."""
+    global _OP_CACHE_ENABLED
+    _OP_CACHE_ENABLED = bool(flag)
+    if not flag:
+        awq_gemm_cache_clear()
+
+
+def awq_gemm_cache_info() -> dict:
+    return {"entries": len(_op_cache), "bytes": _op_cache_bytes, "enabled": _OP_CACHE_ENABLED}
+
+
+def _op_cached_repack(qweight, scales, qzeros, K, N, g):
+    """The op's repacked copy of (qweight, scales, qzeros), made on a miss; None if unsupported / disabled / capturing."""
+    global _op_cache_bytes
+    if not _OP_CACHE_ENABLED or scales.dtype != torch.float16:
+        return None
+    key = (qweight.device.index, qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(), K, N, g)
+    ent = _op_cache.get(key)
+    versions = (qweight._version, scales._version, qzeros._version)
+    if ent is not None:
+        packed, vers, refs = ent
+        if vers == versions and not any(r.expired() for r in refs):
+            return packed
+        del _op_cache[key]
+        _op_cache_bytes -= packed.numel()
+    if torch.cuda.is_current_stream_capturing():
+        return None                                   # fill on an eager (warm-up) call only
+    nbytes = _lib.load().awq_repacked_bytes(K, N, g, _lib.DTYPE_F16)
+    if nbytes == 0 or _op_cache_bytes + nbytes > _OP_CACHE_MAX_BYTES:
+        return None
+    packed = awq_repack(qweight, scales, qzeros)
+    if packed is None:
+        return None
+    refs = tuple(StorageWeakRef(t.untyped_storage()) for t in (qweight, scales, qzeros))
+    _op_cache[key] = (packed, versions, refs)
+    _op_cache_bytes += nbytes
+    return packed
 
 
 # --------------------------------------------------------------------------- implementations (HIP tensors)
@@ -127,11 +196,18 @@ def _gemm_impl(input, qweight, scales, qzeros, bias, split_k_iters, variant=_lib
     lib = _lib.load()
     dev = input.device
     with _on_device(dev):
+        if variant == _lib.GEMM_AUTO and M > 0 and ldx % 8 == 0 and input.data_ptr() % 16 == 0:
+            packed = _op_cached_repack(qweight, scales, qzeros, K, N, g)
+            if packed is not None:
+                try:
+                    return awq_gemm_repacked(input, packed, K, N, g, bias)
+                except AwqHipError:                   # e.g. 32 rows on a very wide strip: no repacked variant
+                    pass
         y = torch.empty((M, N), dtype=scales.dtype, device=dev)
         if M == 0:
             return y
         stream = torch.cuda.current_stream(dev).cuda_stream
-        ws = _workspace(dev)
+        ws = _workspace(dev, stream)
         need = lib.awq_gemm_workspace_bytes(M, K, N, g, _DTYPE_CODE[scales.dtype])
         if need > ws.numel():
             # prefill-sized call on a large matrix: room for the on-the-fly re-layout; a per-call buffer from the caching
@@ -229,6 +305,17 @@ def awq_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor
     return packed
 
 
+def check_packed(packed: torch.Tensor, K: int, N: int, group_size: int, dev: torch.device) -> None:
+    """A repacked buffer is opaque bytes: the kernels index it from (K, N, group_size) alone, so a mismatching buffer would be
+    read out of bounds.  Refuse anything but a uint8 tensor of exactly awq_repacked_bytes(K, N, group_size) on `dev`."""
+    need = _lib.load().awq_repacked_bytes(K, N, group_size, _lib.DTYPE_F16)
+    if need == 0:
+        raise AwqHipError(f"awq repacked layout does not support K={K} N={N} group_size={group_size} (fp16, K % 128 == 0, group_size % 128 == 0)")
+    if packed.dtype != torch.uint8 or packed.numel() != need or not packed.is_contiguous() or packed.device != dev:
+        raise RuntimeError(f"awq: repacked buffer must be a contiguous uint8 tensor of {need} bytes on {dev} for K={K} N={N} "
+                           f"group_size={group_size}, got {packed.dtype} x {packed.numel()} on {packed.device}")
+
+
 def awq_gemm_repacked(input: torch.Tensor, packed: torch.Tensor, K: int, N: int, group_size: int,
                       bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = input @ W (+ bias) from the repacked copy, any M (GEMV passes of 32 rows up to 160 rows, the MFMA-bound
@@ -243,6 +330,7 @@ def awq_gemm_repacked(input: torch.Tensor, packed: torch.Tensor, K: int, N: int,
     ldx = input.stride(0) if M > 1 else max(input.stride(0), K)
     lib = _lib.load()
     dev = input.device
+    check_packed(packed, K, N, group_size, dev)
     with _on_device(dev):
         y = torch.empty((M, N), dtype=torch.float16, device=dev)
         rc = lib.awq_gemm_repacked(_vp(input), ldx, _vp(packed), _vp(bias), _vp(y), M, K, N, group_size, _lib.DTYPE_F16,
