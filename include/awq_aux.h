@@ -18,10 +18,6 @@ extern "C" {
 /* h[rows, H] += delta (if delta != NULL, written back) ; out = rmsnorm(h) * w   (layers/layernorm.py RMSNorm with residual) */
 int awq_aux_add_rmsnorm(void* h, const void* delta, const void* w, void* out, int64_t rows, int64_t H, float eps, void* stream);
 
-/* neox rotary embedding in place on the q / k heads of qkv[B, (Hq + 2 Hkv) D]; k, v of the token -> caches [B, Hkv, S, D] at pos[b] */
-int awq_aux_rope_kv(void* qkv, const int64_t* pos, const float* cos_table, const float* sin_table, void* k_cache, void* v_cache,
-                    int64_t B, int64_t Hq, int64_t Hkv, int64_t D, int64_t S, void* stream);
-
 /* RoPE + KV-cache write + attention of ONE new token per sequence, in one launch (models/llama.py:188-199: rotary_emb, then
  * RadixAttention decode).  qkv[B, (Hq + 2 Hkv) D] is read only; k, v of the token are stored at pos[b] (which must be < S) and
  * out[B, Hq D] = softmax(scale q K^T) V over cache slots 0..pos[b].  D in {64, 128}, Hq % Hkv == 0.

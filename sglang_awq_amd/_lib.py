@@ -28,7 +28,7 @@ EXPORTS = (
     "awq_gemm_repacked",
 )
 # include/awq_aux.h (decode-harness helpers, not part of the operator boundary)
-AUX_EXPORTS = ("awq_aux_add_rmsnorm", "awq_aux_rope_kv", "awq_aux_decode_attention", "awq_aux_decode_attention_workspace_bytes",
+AUX_EXPORTS = ("awq_aux_add_rmsnorm", "awq_aux_decode_attention", "awq_aux_decode_attention_workspace_bytes",
                "awq_aux_argmax_advance", "awq_aux_silu_mul",
                "awq_aux_gemv_repacked_fused")
 ABI_VERSION = 1
@@ -79,8 +79,6 @@ def _bind(L):
     L.awq_gemm_repacked.restype = ci
     L.awq_aux_add_rmsnorm.argtypes = [vp, vp, vp, vp, i64, i64, ctypes.c_float, vp]
     L.awq_aux_add_rmsnorm.restype = ci
-    L.awq_aux_rope_kv.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp]
-    L.awq_aux_rope_kv.restype = ci
     L.awq_aux_decode_attention.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, ctypes.c_float, ci, vp, sz, vp]
     L.awq_aux_decode_attention_workspace_bytes.argtypes = [i64, i64, i64, ci]
     L.awq_aux_decode_attention_workspace_bytes.restype = sz

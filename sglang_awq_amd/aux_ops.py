@@ -1,4 +1,4 @@
-"""ctypes wrappers of include/awq_aux.h: fused RMSNorm(+residual), RoPE + KV-cache write, SiLU-and-mul for the
+"""ctypes wrappers of include/awq_aux.h: fused RMSNorm(+residual), RoPE + KV-cache write + attention, SiLU-and-mul for the
 decode harness (sglang_awq_amd/llama.py).  fp16 HIP tensors, launch-only (graph-capturable)."""
 from __future__ import annotations
 
@@ -25,16 +25,6 @@ def add_rmsnorm(h: torch.Tensor, delta: Optional[torch.Tensor], weight: torch.Te
     rc = _lib.load().awq_aux_add_rmsnorm(_vp(h), _vp(delta), _vp(weight), _vp(out), h.shape[0], h.shape[1], float(eps), _stream(h))
     _lib.check(rc, "awq_aux_add_rmsnorm")
     return out
-
-
-def rope_kv(qkv: torch.Tensor, pos: torch.Tensor, cos_table: torch.Tensor, sin_table: torch.Tensor, k_cache: torch.Tensor,
-            v_cache: torch.Tensor, num_heads: int, num_kv_heads: int, head_dim: int) -> None:
-    """Rotate q / k of qkv [B, (Hq + 2 Hkv) D] in place and write this token's k, v into the caches [Bmax, Hkv, S, D]."""
-    assert qkv.dtype == torch.float16 and qkv.is_contiguous() and pos.dtype == torch.int64
-    assert k_cache.is_contiguous() and v_cache.is_contiguous() and cos_table.dtype == torch.float32
-    rc = _lib.load().awq_aux_rope_kv(_vp(qkv), _vp(pos), _vp(cos_table), _vp(sin_table), _vp(k_cache), _vp(v_cache), qkv.shape[0],
-                                     num_heads, num_kv_heads, head_dim, k_cache.shape[2], _stream(qkv))
-    _lib.check(rc, "awq_aux_rope_kv")
 
 
 _attn_ws = {}

@@ -166,6 +166,8 @@ class AWQLinearMethod(LinearMethodBase):
             K, N, g = qweight.shape[0], qweight.shape[-1] * self.quant_config.pack_factor, qweight.shape[0] // max(scales.shape[0], 1)
         out_shape = x.shape[:-1] + (N,)
         reshaped_x = x.reshape(-1, x.shape[-1])
+        if reshaped_x.shape[0] == 0:
+            return x.new_empty(out_shape)
         if packed is not None and reshaped_x.shape[0] <= self.REPACKED_MAX_M and reshaped_x.shape[0] > 0:
             if released is not None:
                 out = ops.awq_gemm_repacked(reshaped_x, packed, K, N, g, bias)     # no checkpoint-layout route left: errors propagate

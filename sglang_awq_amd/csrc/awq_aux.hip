@@ -86,36 +86,8 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(half_t* __restrict__ h
   }
 }
 
-// In place: neox-style rotary embedding on the q and k heads of qkv[b], then k / v of this token into the
-// caches [B, Hkv, S, D] at position pos[b].  One workgroup per (token, head); D / 2 threads.
-__global__ void rope_kv_kernel(half_t* __restrict__ qkv, const int64_t* __restrict__ pos, const float* __restrict__ cos_t,
-                               const float* __restrict__ sin_t, half_t* __restrict__ kc, half_t* __restrict__ vc, int Hq, int Hkv, int D,
-                               int S) {
-  const int b = blockIdx.y, head = blockIdx.x, t = threadIdx.x, half = D / 2;
-  const int64_t p_raw = pos[b];
-  const bool in_range = p_raw >= 0 && p_raw < S;                    // a position outside the cache: rotate with the clamped angle, store nothing
-  const int64_t p = p_raw < 0 ? 0 : (p_raw < S ? p_raw : S - 1);
-  half_t* row = qkv + (size_t)b * (Hq + 2 * Hkv) * D + (size_t)head * D;
-  if (head < Hq + Hkv) {
-    const float c = cos_t[p * half + t], s = sin_t[p * half + t];
-    const float x1 = (float)row[t], x2 = (float)row[t + half];
-    const half_t o1 = (half_t)(x1 * c - x2 * s), o2 = (half_t)(x2 * c + x1 * s);
-    row[t] = o1;
-    row[t + half] = o2;
-    if (head >= Hq && in_range) {
-      half_t* dst = kc + (((size_t)b * Hkv + (head - Hq)) * S + p) * D;
-      dst[t] = o1;
-      dst[t + half] = o2;
-    }
-  } else if (in_range) {
-    half_t* dst = vc + (((size_t)b * Hkv + (head - Hq - Hkv)) * S + p) * D;
-    dst[t] = row[t];
-    dst[t + half] = row[t + half];
-  }
-}
-
 // Single-token attention for one (sequence, query head) per workgroup, with the rotary embedding and the
-// KV-cache write of the new token folded in (what rope_kv_kernel + an SDPA launch did in two).  The new
+// KV-cache write of the new token folded in (what a rotary-embedding / cache-write launch + an SDPA launch would do in two).  The new
 // token's k / v come straight from qkv (every workgroup of a GQA group rotates its own copy; the group's first
 // head stores them), so no workgroup reads what another one writes in the same launch.
 // Latency-bound at decode sizes (a few hundred KB per workgroup), so the structure minimises dependent round
@@ -385,15 +357,6 @@ int awq_aux_add_rmsnorm(void* h, const void* delta, const void* w, void* out, in
   if (rows <= 0 || H <= 0 || H % 8) return AWQ_ERR_BAD_SHAPE;
   hipLaunchKernelGGL(awq::add_rmsnorm_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (awq::half_t*)h,
                      (const awq::half_t*)delta, (const awq::half_t*)w, (awq::half_t*)out, (int)H, eps);
-  return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
-}
-
-int awq_aux_rope_kv(void* qkv, const int64_t* pos, const float* cos_t, const float* sin_t, void* k_cache, void* v_cache, int64_t B,
-                    int64_t Hq, int64_t Hkv, int64_t D, int64_t S, void* stream) {
-  if (!qkv || !pos || !cos_t || !sin_t || !k_cache || !v_cache) return AWQ_ERR_NULL_POINTER;
-  if (B <= 0 || Hq <= 0 || Hkv <= 0 || D <= 0 || D % 2 || D / 2 > 1024 || S <= 0) return AWQ_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(awq::rope_kv_kernel, dim3((unsigned)(Hq + 2 * Hkv), (unsigned)B), dim3((unsigned)(D / 2)), 0, (hipStream_t)stream,
-                     (awq::half_t*)qkv, pos, cos_t, sin_t, (awq::half_t*)k_cache, (awq::half_t*)v_cache, (int)Hq, (int)Hkv, (int)D, (int)S);
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 

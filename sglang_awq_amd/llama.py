@@ -283,12 +283,12 @@ class GraphedDecoder:
         self._set_attention_splits()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        if self.start_pos + self.steps_taken + warmup + 1 > self.model.max_seq:
-            raise ValueError("not enough room in the KV cache for the warm-up and capture steps")
+        if self.start_pos + self.steps_taken + warmup > self.model.max_seq:
+            raise ValueError("not enough room in the KV cache for the warm-up steps")
         with torch.cuda.stream(s):
             for _ in range(warmup):
                 self._step()
-        self.steps_taken += warmup + 1
+        self.steps_taken += warmup                # the captured step itself does not execute
         torch.cuda.current_stream().wait_stream(s)
         graph = torch.cuda.CUDAGraph()
         try:

@@ -1,24 +1,75 @@
-"""`sgl_kernel`-shaped module for the AWQ path.
+"""`sgl_kernel`-shaped module for the AWQ path, and the zero-edit binding on the reference's HIP branch.
 
 The reference binds its AWQ op by name at import time (awq.py:62-77):
     CUDA / XPU:  from sgl_kernel import awq_dequantize
     HIP:         from ...awq_triton import awq_dequantize_triton as awq_dequantize
-`install()` makes `import sgl_kernel; sgl_kernel.awq_dequantize / sgl_kernel.awq_gemm` resolve to the
-gfx950 ops: it attaches the two names to an already-imported real `sgl_kernel` (whose ROCm build
-registers no AWQ op at all, common_extension_rocm.cc:21-198) or, when no `sgl_kernel` is
-importable, publishes this module under that name.  See INTEGRATION.md for the one-line change on
-the reference's HIP branch.
+and `AWQLinearMethod.apply` reads that module global at CALL time (awq.py:446).  `install()` therefore
+
+  1. makes `import sgl_kernel; sgl_kernel.awq_dequantize / sgl_kernel.awq_gemm` resolve to the gfx950 ops: it attaches
+     the two names to an already-imported real `sgl_kernel` (whose ROCm build registers no AWQ op at all,
+     common_extension_rocm.cc:21-198) or, when no `sgl_kernel` is importable, publishes this module under that name
+     — what the `_is_cuda` / `_is_xpu` branches pick up;
+  2. rebinds the global `awq_dequantize` of `sglang.srt.layers.quantization.awq` to `torch.ops.sgl_kernel.awq_dequantize`
+     — what the `_is_hip` branch needs, since it bound the Triton kernel.  If that module is already imported it is
+     patched in place; otherwise a post-import hook patches it when it is imported later.  No file of the reference is
+     edited; `uninstall()` restores the original binding;
+  3. optionally (`register_config=True`) puts this package's AWQConfig under "awq" in the reference's method registry
+     (quantization/__init__.py:58), so new layers get this package's AWQLinearMethod (fused kernel, one launch) instead
+     of dequantise + matmul.
 """
 import importlib
+import importlib.abc
 import sys
 
 from .ops import awq_dequantize, awq_gemm  # noqa: F401  (registers torch.ops.sgl_kernel.* as a side effect)
 
-__all__ = ["awq_dequantize", "awq_gemm", "install"]
+__all__ = ["awq_dequantize", "awq_gemm", "install", "uninstall"]
+
+REFERENCE_AWQ_MODULE = "sglang.srt.layers.quantization.awq"
+REFERENCE_REGISTRY_MODULE = "sglang.srt.layers.quantization"
+_SAVED = "_sglang_awq_amd_saved_awq_dequantize"
 
 
-def install(force_module: bool = False):
-    """Expose awq_dequantize / awq_gemm as attributes of `sgl_kernel`; returns that module."""
+def _patch_reference_awq(mod) -> None:
+    """Point the reference module's `awq_dequantize` global at the gfx950 op (the name apply() resolves per call)."""
+    if getattr(mod, "awq_dequantize", None) is awq_dequantize:
+        return
+    if not hasattr(mod, _SAVED):
+        setattr(mod, _SAVED, getattr(mod, "awq_dequantize", None))
+    mod.awq_dequantize = awq_dequantize
+
+
+class _PatchOnImport(importlib.abc.MetaPathFinder):
+    """Finds the reference's awq module with the remaining finders and wraps its loader so the module is patched right
+    after it has executed (its import-time ladder has run by then)."""
+
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname != REFERENCE_AWQ_MODULE:
+            return None
+        for finder in sys.meta_path:
+            if finder is self or not hasattr(finder, "find_spec"):
+                continue
+            spec = finder.find_spec(fullname, path, target)
+            if spec is None or spec.loader is None or not hasattr(spec.loader, "exec_module"):
+                continue
+            inner = spec.loader.exec_module
+
+            def exec_module(module, _inner=inner):
+                _inner(module)
+                _patch_reference_awq(module)
+
+            spec.loader.exec_module = exec_module
+            return spec
+        return None
+
+
+_hook = None
+
+
+def install(force_module: bool = False, patch_reference: bool = True, register_config: bool = False):
+    """Expose awq_dequantize / awq_gemm as attributes of `sgl_kernel` and (patch_reference) bind the reference's
+    AWQLinearMethod to the gfx950 op on its HIP branch; returns the `sgl_kernel` module."""
+    global _hook
     this = sys.modules[__name__]
     target = sys.modules.get("sgl_kernel")
     if target is None and not force_module:
@@ -28,7 +79,40 @@ def install(force_module: bool = False):
             target = None
     if target is None or force_module:
         sys.modules["sgl_kernel"] = this
-        return this
-    target.awq_dequantize = awq_dequantize
-    target.awq_gemm = awq_gemm
+        target = this
+    else:
+        target.awq_dequantize = awq_dequantize
+        target.awq_gemm = awq_gemm
+    if patch_reference:
+        mod = sys.modules.get(REFERENCE_AWQ_MODULE)
+        if mod is not None:
+            _patch_reference_awq(mod)
+        elif _hook is None:
+            _hook = _PatchOnImport()
+            sys.meta_path.insert(0, _hook)
+    if register_config:
+        from .awq import AWQConfig
+
+        reg = sys.modules.get(REFERENCE_REGISTRY_MODULE)
+        if reg is None:
+            try:
+                reg = importlib.import_module(REFERENCE_REGISTRY_MODULE)
+            except Exception:
+                reg = None
+        for name in ("BASE_QUANTIZATION_METHODS", "QUANTIZATION_METHODS"):
+            table = getattr(reg, name, None) if reg is not None else None
+            if isinstance(table, dict):
+                table["awq"] = AWQConfig
     return target
+
+
+def uninstall() -> None:
+    """Undo install()'s patch of the reference module and remove the post-import hook (the `sgl_kernel` names stay)."""
+    global _hook
+    if _hook is not None and _hook in sys.meta_path:
+        sys.meta_path.remove(_hook)
+    _hook = None
+    mod = sys.modules.get(REFERENCE_AWQ_MODULE)
+    if mod is not None and hasattr(mod, _SAVED):
+        mod.awq_dequantize = getattr(mod, _SAVED)
+        delattr(mod, _SAVED)

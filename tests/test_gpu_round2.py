@@ -1,0 +1,257 @@
+"""Round-2 parity additions (-m gpu): the Llama-2-70B TP = 8 per-rank shapes and the 7B o_proj through both public routes,
+the drop-in op's repacked-copy cache (bit-identity, invalidation, capture behaviour), two streams at once, the decode-harness
+neighbour kernels on their own, awq_dequantize at the DeepSeek kv_b_proj post-load shape, the decoder's position guard."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import awq_ref, c_oracle
+from sglang_awq_amd import _lib, synth
+from tests.util import assert_gemm_close, bits, to_np, to_torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sglang_awq_amd import ops as _ops   # raises if the HIP library is missing: no fallback
+
+    _lib.load()
+    return _ops
+
+
+def _dev(*arrs):
+    return [to_torch(a, DEV) for a in arrs]
+
+
+# BASELINE configs[4]: Llama-2-70B at TP = 8, per-rank (K, N): qkv, o, gate_up, down; plus the 7B o_proj (linear.py:832-837)
+SHAPES = [(8192, 1280), (1024, 8192), (8192, 7168), (3584, 8192), (4096, 4096)]
+
+
+@pytest.mark.parametrize("K,N", SHAPES)
+def test_tp8_per_rank_shapes_via_apply_and_op(ops, K, N):
+    """AWQLinearMethod.apply (repacked copy made at load) and torch.ops.sgl_kernel.awq_gemm (checkpoint tensors; cache on
+    and off) against the exact-sum oracle at decode batch sizes, and against each other bit for bit where they run the
+    same kernel."""
+    from sglang_awq_amd.awq import AWQConfig, AWQLinearMethod
+
+    qw, s, qz = synth.make_awq_weights(K, N, 128, "f16", "A", seed=K + N)
+    method = AWQLinearMethod(AWQConfig(4, 128, True))
+    layer = torch.nn.Module()
+    method.create_weights(layer, K, [N], K, N, torch.float16, weight_loader=None)
+    layer.qweight.data.copy_(to_torch(qw)); layer.qzeros.data.copy_(to_torch(qz)); layer.scales.data.copy_(to_torch(s))
+    layer.to(DEV)
+    method.process_weights_after_loading(layer)
+    assert layer.awq_packed is not None
+    for M in (1, 8, 32):
+        x = synth.make_activations(M, K, "f16", "A", seed=M + K)
+        _, exact = c_oracle.gemm(x, qw, s, qz, want_exact=True)
+        xt = to_torch(x, DEV)
+        y_apply = method.apply(layer, xt)
+        assert_gemm_close(to_np(y_apply), exact, "f16", what=f"apply M={M} K={K} N={N}")
+        ops.awq_gemm_cache_enable(True)
+        y_op = torch.ops.sgl_kernel.awq_gemm(xt, layer.qweight, layer.scales, layer.qzeros, 1)
+        assert torch.equal(y_op, y_apply), f"op (cached repacked copy) != apply, M={M}"
+        ops.awq_gemm_cache_enable(False)
+        try:
+            y_ck = torch.ops.sgl_kernel.awq_gemm(xt, layer.qweight, layer.scales, layer.qzeros, 1)
+        finally:
+            ops.awq_gemm_cache_enable(True)
+        assert_gemm_close(to_np(y_ck), exact, "f16", what=f"op on the checkpoint layout M={M} K={K} N={N}")
+    ops.awq_gemm_cache_clear()
+
+
+def test_op_cache_invalidation_and_capture(ops):
+    """The op's repacked copy follows the weight: an in-place update (version counter), a freed-and-reused address
+    (storage weak reference) and awq_gemm_cache_clear() all lead to fresh results; a miss during stream capture does not
+    fill the cache (and still computes the right thing through the checkpoint-layout kernel)."""
+    K, N = 1024, 2048
+    x = synth.make_activations(4, K, "f16", "A", 9)
+    xt = to_torch(x, DEV)
+    w1 = synth.make_awq_weights(K, N, 128, "f16", "A", 101)
+    w2 = synth.make_awq_weights(K, N, 128, "f16", "A", 202)
+    ops.awq_gemm_cache_enable(True)
+    ops.awq_gemm_cache_clear()
+    qw, s, qz = _dev(*w1)
+    y1 = ops.awq_gemm(xt, qw, s, qz, 1)
+    assert ops.awq_gemm_cache_info()["entries"] == 1
+    assert torch.equal(y1, ops.awq_gemm(xt, qw, s, qz, 1)) and ops.awq_gemm_cache_info()["entries"] == 1
+    _, e1 = c_oracle.gemm(x, *w1, want_exact=True)
+    _, e2 = c_oracle.gemm(x, *w2, want_exact=True)
+    assert_gemm_close(to_np(y1), e1, "f16", what="cached op, first weights")
+    # in-place update of the same tensors (what an RL weight sync does): versions change -> the copy is rebuilt
+    qw.copy_(to_torch(w2[0], DEV)); s.copy_(to_torch(w2[1], DEV)); qz.copy_(to_torch(w2[2], DEV))
+    y2 = ops.awq_gemm(xt, qw, s, qz, 1)
+    assert_gemm_close(to_np(y2), e2, "f16", what="cached op after in-place weight update")
+    assert ops.awq_gemm_cache_info()["entries"] == 1
+    # free the weights, allocate new ones of the same shape (the caching allocator hands the same addresses back)
+    ptrs = (qw.data_ptr(), s.data_ptr(), qz.data_ptr())
+    del qw, s, qz
+    qw, s, qz = _dev(*w1)
+    reused = (qw.data_ptr(), s.data_ptr(), qz.data_ptr()) == ptrs
+    y3 = ops.awq_gemm(xt, qw, s, qz, 1)
+    assert_gemm_close(to_np(y3), e1, "f16", what=f"cached op after free + realloc (addresses reused: {reused})")
+    # explicit clear
+    ops.awq_gemm_cache_clear()
+    assert ops.awq_gemm_cache_info() == {"entries": 0, "bytes": 0, "enabled": True}
+    # capture-time miss: not cached, still right
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.awq_gemm_cache_enable(False)
+        ops.awq_gemm(xt, qw, s, qz, 1)                 # warm-up of the checkpoint-layout route on the capture stream (workspace)
+        ops.awq_gemm_cache_enable(True)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        yc = ops.awq_gemm(xt, qw, s, qz, 1)
+    assert ops.awq_gemm_cache_info()["entries"] == 0
+    g.replay()
+    torch.cuda.synchronize()
+    assert_gemm_close(to_np(yc), e1, "f16", what="op captured with an empty cache")
+    # eager call fills it; a graph captured afterwards replays the repacked kernel, bit-identical to awq_gemm_repacked
+    y4 = ops.awq_gemm(xt, qw, s, qz, 1)
+    assert ops.awq_gemm_cache_info()["entries"] == 1
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=side):
+        yc2 = ops.awq_gemm(xt, qw, s, qz, 1)
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(yc2, y4) and torch.equal(y4, ops.awq_gemm_repacked(xt, ops.awq_repack(qw, s, qz), K, N, 128))
+    ops.awq_gemm_cache_clear()
+
+
+def test_two_streams_do_not_share_split_k_scratch(ops):
+    """The checkpoint-layout split-K kernel keeps arrival counters and fp32 slabs in a workspace: one per (device, stream).
+    Two streams run M <= 16 GEMMs at the same time, many times over; every result must equal the single-stream one."""
+    K, N = 4096, 4096
+    ops.awq_gemm_cache_enable(False)
+    try:
+        wa = _dev(*synth.make_awq_weights(K, N, 128, "f16", "A", 11))
+        wb = _dev(*synth.make_awq_weights(K, N, 128, "f16", "A", 12))
+        xa = to_torch(synth.make_activations(3, K, "f16", "A", 13), DEV)
+        xb = to_torch(synth.make_activations(16, K, "f16", "A", 14), DEV)
+        ya = ops.awq_gemm(xa, *wa, 1)
+        yb = ops.awq_gemm(xb, *wb, 1)
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs_a, outs_b = [], []
+        for _ in range(50):
+            with torch.cuda.stream(s1):
+                outs_a.append(ops.awq_gemm(xa, *wa, 1))
+            with torch.cuda.stream(s2):
+                outs_b.append(ops.awq_gemm(xb, *wb, 1))
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, ya) for o in outs_a) and all(torch.equal(o, yb) for o in outs_b)
+        keys = {k for k in ops._workspaces if k[0] == 0}
+        assert len({k[1] for k in keys}) >= 3            # default stream + the two side streams each got their own
+    finally:
+        ops.awq_gemm_cache_enable(True)
+
+
+@pytest.mark.parametrize("H", [256, 4096, 8192, 8200, 11008])
+@pytest.mark.parametrize("with_delta", [False, True])
+def test_add_rmsnorm_kernel_vs_fp32(H, with_delta):
+    """awq_aux_add_rmsnorm on its own: 1, 2, 4 register chunks per thread (H = 256, 4096, 8192), the strided two-pass route
+    (H > 8192), a ragged width (8200 = 1025 chunks of 8), with and without the residual add; fp32 torch reference with the
+    kernel's rounding points (fp16 add, fp32 sum of squares, fp16(v * inv) * w)."""
+    from sglang_awq_amd import aux_ops
+
+    rows, eps = 5, 1e-5
+    g = torch.Generator(device="cpu"); g.manual_seed(H + with_delta)
+    h = torch.randn(rows, H, generator=g).half()
+    d = (0.5 * torch.randn(rows, H, generator=g)).half()
+    w = (1.0 + 0.25 * torch.randn(H, generator=g)).half()
+    hd = h.to(DEV).clone()
+    out = aux_ops.add_rmsnorm(hd, d.to(DEV) if with_delta else None, w.to(DEV), eps)
+    v = (h + d) if with_delta else h                                   # fp16 add
+    assert torch.equal(hd.cpu(), v), "h must hold h + delta afterwards (or be untouched)"
+    inv = torch.rsqrt((v.double() ** 2).mean(-1, keepdim=True) + eps)
+    want = ((v.double() * inv).half() * w).double()                    # fp16(v * inv) * w, fp16 product
+    got = out.cpu().double()
+    # v_rsq_f32 is good to ~1 ulp of fp32: fp16(v * inv) may land on the neighbouring half for a few elements
+    ulp = 2.0 ** (torch.floor(torch.log2(want.abs().clamp_min(2.0 ** -14))) - 10)
+    assert ((got - want).abs() <= 1.01 * ulp * (1 + w.double().abs())).all()
+    assert float((got != want).double().mean()) < 0.02
+
+
+@pytest.mark.parametrize("B,I", [(1, 11008), (3, 128), (32, 28672), (7, 1024)])
+def test_silu_mul_kernel_vs_torch(B, I):
+    from sglang_awq_amd import aux_ops
+
+    g = torch.Generator(device="cpu"); g.manual_seed(B * 7 + I)
+    gu = (2.0 * torch.randn(B, 2 * I, generator=g)).half()
+    got = aux_ops.silu_mul(gu.to(DEV)).cpu()
+    gate, up = gu[:, :I].float(), gu[:, I:]
+    silu = (gate / (1.0 + torch.exp(-gate))).half()                    # silu in fp32 rounded to fp16 ...
+    want = silu * up                                                   # ... then an fp16 product
+    diff = (got.double() - want.double()).abs()
+
+    def ulp16(t):
+        return 2.0 ** (torch.floor(torch.log2(t.double().abs().clamp_min(2.0 ** -14))) - 10)
+    # __expf vs exp: the silu may land on the neighbouring half (one ulp of the silu, scaled by |up|), then one product rounding
+    assert (diff <= 1.01 * (ulp16(silu) * up.double().abs() + ulp16(want))).all()
+    assert float((got != want).double().mean()) < 0.02
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_dequantize_deepseek_kv_b_proj_post_load_shapes(ops, dt):
+    """deepseek_v2.py:3433-3450 / longcat_flash.py:645-655 call awq_dequantize(qweight, scales, qzeros).T on kv_b_proj after
+    loading: K = kv_lora_rank = 512, N = heads x (qk_nope 128 + v 128) = 32768 at TP = 1 and 4096 at TP = 8; bit-exact
+    against the oracle in the scales' dtype, transposed view included."""
+    for N in (32768, 4096):
+        qw, s, qz = synth.make_awq_weights(512, N, 128, dt, "F", seed=N)
+        w = ops.awq_dequantize(*_dev(qw, s, qz))
+        want = awq_ref.awq_dequantize(qw, s, qz)
+        assert np.array_equal(bits(to_np(w)), bits(want))
+        assert np.array_equal(bits(to_np(w.T.contiguous())), bits(np.ascontiguousarray(want.T)))
+
+
+def test_released_checkpoint_tensors(ops, monkeypatch):
+    """SGLANG_AWQ_AMD_KEEP_CHECKPOINT=0: after the re-layout the checkpoint tensors are released; apply() runs every batch size
+    from the repacked copy (32 rows on a wide strip included) and reproduces the kept-checkpoint results bit for bit."""
+    from sglang_awq_amd.awq import AWQConfig, AWQLinearMethod
+
+    K, N = 1024, 2048
+    qw, s, qz = synth.make_awq_weights(K, N, 128, "f16", "A", 77)
+
+    def build():
+        method = AWQLinearMethod(AWQConfig(4, 128, True))
+        layer = torch.nn.Module()
+        method.create_weights(layer, K, [N], K, N, torch.float16, weight_loader=None)
+        layer.qweight.data.copy_(to_torch(qw)); layer.qzeros.data.copy_(to_torch(qz)); layer.scales.data.copy_(to_torch(s))
+        layer.to(DEV)
+        method.process_weights_after_loading(layer)
+        return method, layer
+
+    m_keep, l_keep = build()
+    monkeypatch.setenv("SGLANG_AWQ_AMD_KEEP_CHECKPOINT", "0")
+    m_rel, l_rel = build()
+    assert l_rel.qweight.numel() == 0 and l_rel.scales.numel() == 0 and l_rel.awq_shape == (K, N, 128)
+    b = to_torch(synth.make_bias(N, "f16", 5), DEV)
+    for M in (1, 16, 32, 200, 1030):
+        x = to_torch(synth.make_activations(M, K, "f16", "A", M), DEV)
+        assert torch.equal(m_rel.apply(l_rel, x, b), m_keep.apply(l_keep, x, b)), M
+    assert m_rel.apply(l_rel, torch.empty(0, K, dtype=torch.float16, device=DEV)).shape == (0, N)
+
+
+def test_graphed_decoder_refuses_to_leave_the_kv_cache():
+    from sglang_awq_amd.awq import AWQConfig
+    from sglang_awq_amd.llama import GraphedDecoder, LlamaConfig, LlamaForCausalLM
+
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=1, num_attention_heads=4, num_key_value_heads=2,
+                      vocab_size=512, max_position_embeddings=64)
+    with torch.device(DEV):
+        model = LlamaForCausalLM(cfg, AWQConfig(4, 128, True), max_batch=2, max_seq=16)
+    model.init_synthetic_(seed=1)
+    with pytest.raises(ValueError):
+        GraphedDecoder(model, 2, start_pos=16)
+    dec = GraphedDecoder(model, 2, start_pos=10).capture(warmup=1)      # the warm-up step consumed position 10 (capture runs nothing)
+    dec.run(5)                                                          # 11 .. 15: the last slot of the cache
+    with pytest.raises(ValueError):
+        dec.run(1)
+    assert int(dec.pos.max()) == 16                                     # the device-side counter never went further
+    dec.reset(3)
+    dec.run(2)
+    assert int(dec.pos.max()) == 5

@@ -175,3 +175,38 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.AwqHipError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_repacked_entry_points_refuse_shapes_without_a_layout(lib):
+    """awq_gemm_repacked indexes `packed` from (K, N, group_size) alone: shapes the fragment-major layout does not exist for
+    (bf16 / fp32, K % 128, group_size % 128) must come back as AWQ_ERR_BAD_VARIANT before anything is launched."""
+    buf = (ctypes.c_char * 8192)()
+    p = (ctypes.cast(buf, ctypes.c_void_p).value + 15) & ~15
+    vp = ctypes.c_void_p
+    assert lib.awq_repacked_bytes(4096, 11008, 128, 0) == 688 * 32 * 1024 + 688 * 32 * 64
+    assert lib.awq_repacked_bytes(4096, 11008, 64, 0) == 0 and lib.awq_repacked_bytes(4096, 11008, 128, 1) == 0
+    assert lib.awq_repacked_bytes(192, 64, 64, 0) == 0
+    # K = 192 (not a multiple of 128), group 64: legal AWQ shape, no repacked layout -> -7, for every M route
+    for M in (1, 16, 32, 64, 100, 200, 2048):
+        assert lib.awq_gemm_repacked(vp(p), 192, vp(p), None, vp(p), M, 192, 64, 64, 0, None) == -7, M
+    assert lib.awq_gemm_repacked(vp(p), 4096, vp(p), None, vp(p), 128, 4096, 4096, 128, 1, None) == -7      # bf16
+    assert lib.awq_gemm_repacked(vp(p), 4096, vp(p), None, vp(p), 128, 4096, 4096, 64, 0, None) == -7       # g = 64
+    assert lib.awq_gemm_repacked(None, 4096, vp(p), None, vp(p), 1, 4096, 4096, 128, 0, None) == -1
+    assert lib.awq_aux_gemv_repacked_fused(vp(p), 192, vp(p), vp(p), 1, 192, 64, 64, 0, None, None, None, None, 0.0, 1, None) == -7
+
+
+def test_python_shim_checks_the_repacked_buffer():
+    """ops.check_packed: a repacked buffer of the wrong size / dtype / device is refused before any kernel could read past it."""
+    from sglang_awq_amd import ops
+
+    cpu = torch.device("cpu")
+    need = 688 * 32 * 1024 + 688 * 32 * 64
+    ops.check_packed(torch.empty(need, dtype=torch.uint8), 4096, 11008, 128, cpu)
+    with pytest.raises(RuntimeError):
+        ops.check_packed(torch.empty(need - 64, dtype=torch.uint8), 4096, 11008, 128, cpu)
+    with pytest.raises(RuntimeError):
+        ops.check_packed(torch.empty(need // 4, dtype=torch.int32), 4096, 11008, 128, cpu)
+    with pytest.raises(RuntimeError):
+        ops.check_packed(torch.empty(need, dtype=torch.uint8), 4096, 11008, 256, cpu)     # same K, N, other group size
+    with pytest.raises(ops.AwqHipError):
+        ops.check_packed(torch.empty(16, dtype=torch.uint8), 4096, 11008, 64, cpu)        # no layout for g = 64

@@ -145,3 +145,24 @@ def test_shape_contract_errors():
         awq_ref.awq_gemm(synth.make_activations(2, 128), qw, s, qz, split_k_iters=3)
     with pytest.raises(ValueError):
         awq_ref.awq_gemm(synth.make_activations(2, 128), qw, s, qz, split_k_iters=64)
+
+
+def test_torch_cpu_baseline_dequantize_bit_exact(small):
+    """oracle/torch_cpu.dequantize_cpu — the eager-torch restatement that bench.py's cpu_baseline leg times — against the
+    reference-generated golden outputs, bit for bit (fp16 and bf16 cases, every group size in the file)."""
+    from oracle import torch_cpu
+
+    checked = 0
+    for i in range(int(small["n_dequant"])):
+        dt = str(small[f"dq{i}_dtype"])
+        if dt not in ("f16", "bf16"):
+            continue
+        qw, s, qz, want = (small[f"dq{i}_{k}"] for k in ("qweight", "scales", "qzeros", "out"))
+        got = torch_cpu.to_np(torch_cpu.dequantize_cpu(torch_cpu.from_np(qw), torch_cpu.from_np(s, bf16=dt == "bf16"), torch_cpu.from_np(qz)))
+        assert np.array_equal(np.ascontiguousarray(got).view(np.uint8), np.ascontiguousarray(want).view(np.uint8)), f"case {i} ({dt})"
+        checked += 1
+    assert checked >= 8
+    for i in range(int(small["n_verbatim"])):
+        qw, s, qz, want = (small[f"verb{i}_{k}"] for k in ("qweight", "scales", "qzeros", "out"))
+        got = torch_cpu.to_np(torch_cpu.dequantize_cpu(torch_cpu.from_np(qw), torch_cpu.from_np(s), torch_cpu.from_np(qz)))
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16))

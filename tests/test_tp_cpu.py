@@ -224,3 +224,38 @@ def test_tp2_gloo_column_row_allreduce(tmp_path):
     full_act = synth.make_activations(M, inter, "f16", "A", 6, x_std=0.05)
     want2 = awq_ref.row_parallel_reference(full_act, dq, ds, dz, 2)
     assert np.abs(outs[0]["y2"].double().numpy() - want2).max() < 2e-3
+
+
+def _bench_rehearsal(extra, world=2):
+    """bench.py's N > 1 path on CPU: gloo collectives, kernels stubbed out (BENCH_TEST_CPU=1) — shapes, sharding, the
+    all-reduce and the JSON contract, not numbers."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_TEST_BACKEND="gloo", BENCH_TEST_CPU="1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
+           "--sets", "2", "--cpu-seconds", "0"] + extra
+    res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_strong_scaling_rehearsal_gloo():
+    out = _bench_rehearsal(["--scaling", "strong"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 3
+    # SURVEY §8(e): column N / tp = 5504, row K / tp = 2048, all-reduce payload [M, 11008] fp16
+    assert out["config"]["per_rank_linears"] == ["col 4096x5504", "row 2048x11008"]
+    assert out["config"]["collective"]["all_reduce_bytes"] == [11008 * 2]
+    assert out["config"]["graph_replay"] is False and out["value"] > 0
+
+
+def test_bench_70b_tp8_shapes_rehearsal_gloo():
+    out = _bench_rehearsal(["--shapes", "70b-tp8"])
+    assert out["config"]["per_rank_linears"] == ["col 8192x1280", "row 1024x8192", "col 8192x7168", "row 3584x8192"]
+    assert out["config"]["collective"]["all_reduce_bytes"] == [8192 * 2, 8192 * 2]
+    assert out["scaling"] == "weak"
