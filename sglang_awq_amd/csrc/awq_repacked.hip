@@ -368,11 +368,11 @@ int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
   // 16 waves, M <= 16: the restructured straight-line kernel (gemv_rp2_kernel: x and zs staged through wave-private LDS by the
   // same few loads, ring of two weight loads per wave, round-robin issue) wherever it has an instantiation; AWQ_RP2=0 /
   // AWQ_RP2_D=0 (every load up front) are A/B knobs for tools/kbench.
-  // Ring depth: two loads in flight per wave for one row (6.73 -> 6.37 us against every load up front, tools/gemv_lab); with
-  // more rows the x staging loads share the queue and issuing everything up front measured better (M = 4: 7.4 vs 7.7 us).
+  // Ring depth: two loads in flight per wave (4096 x 11008: 6.73 -> 6.37 us at M = 1 against every load up front in
+  // tools/gemv_lab; kbench at M = 4: 7.03 vs 7.14, 11008 x 4096 at M = 4: 8.36 vs 8.48).  AWQ_RP2_D=0: everything up front.
   static const int env_rp2 = rp_env("AWQ_RP2", 1), env_d = rp_env("AWQ_RP2_D", -1);
   if (env_rp2 && W == 16 && !two_tiles && nt && env_t != 0) {
-    const int depth = env_d >= 0 ? env_d : (a.M == 1 ? 2 : 0);
+    const int depth = env_d >= 0 ? env_d : 2;
     if (rp2_launch<0>(G, (KB + 15) / 16, a, packed, NG, depth, nwg)) return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
   }
   if (W == 16 && env_waves != 16 && (T < 0 || (T == 0 && (KB + 15) / 16 <= 6))) {   // straight-line did not fit: 8 waves measured better than the 16-wave loop

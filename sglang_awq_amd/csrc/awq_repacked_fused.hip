@@ -60,7 +60,7 @@ int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed) {
   }
   size_t lds = (size_t)W * a.M * 16 * G * sizeof(float);
   if (!norm) {                                                               // SiLU-mul epilogue only: the restructured kernel when it has an instantiation
-    if (rp2_launch<1>(G, T, a, packed, NG, a.M == 1 ? 2 : 0, nwg)) return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+    if (rp2_launch<1>(G, T, a, packed, NG, 2, nwg)) return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
   }
   if (!rp_fits_fused(G, T, PRO, a.silu_mul)) return AWQ_ERR_BAD_VARIANT;
   if (norm) lds += (size_t)W * a.M * (T * 128 + 8) * 2 + (size_t)W * PRO * 4 * sizeof(float);

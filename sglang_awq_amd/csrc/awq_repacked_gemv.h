@@ -357,10 +357,11 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
       const unsigned char* sz;
       int dz;
       zs_chunk(j, sz, dz);
+      // k-blocks past K (ragged last wave) are whole k-blocks: their x chunks are read from column 0 instead (in bounds) and
+      // their scale is forced to 0 after staging — no select on the loaded value, which would wait for the load right here
       const bool xin = isx && (kb0 * 128 + id * 8 < K);
       const unsigned char* sx = (const unsigned char*)(x + (xin ? (size_t)kb0 * 128 + id * 8 : 0));
       sv[i] = *(const u32x4_t*)(isx ? sx : sz);
-      if (isx && !xin) sv[i] = (u32x4_t){0u, 0u, 0u, 0u};               // k-blocks past K (ragged last wave): x = 0
       sdst[i] = id >= T * 16 + NZ ? dump : isx ? id * 16 : dz;
     }
   } else {
@@ -370,7 +371,6 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
       const int row = id / (T * 16), cc = id - row * (T * 16);
       const bool xin = id < nx && (kb0 * 128 + cc * 8 < K);
       sv[i] = *(const u32x4_t*)(x + (xin ? (size_t)row * ldx + (size_t)kb0 * 128 + cc * 8 : 0));
-      if (!xin) sv[i] = (u32x4_t){0u, 0u, 0u, 0u};                       // k-blocks past K (ragged last wave): x = 0
       sdst[i] = id < nx ? (row * XS + cc * 8) * 2 : dump;
     }
     const unsigned char* sz;
@@ -397,8 +397,21 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < CHT; ++i) *(u32x4_t*)(stg + sdst[i]) = sv[i];
+  if (kb0 + T > KB) {
+    // ragged last wave (wave-uniform, rare): a k-block past K must contribute nothing.  Its weights were re-read from the last
+    // valid k-block and its x from column 0 (both finite); overwrite its staged (scale | 1024 + zero) words with scale 0, so
+    // every dequantised value is exactly 0.  A second, predicated LDS store behind the first: no select on loaded data.
+    if (lane < NZ) {
+      const int c = lane / (T * 4), rem = lane - c * (T * 4), t = rem >> 2, part = rem & 3;
+      if (kb0 + t >= KB) *(u32x4_t*)(stg + xbytes + ((c * T + t) * 16 + part * 4) * 4) = (u32x4_t){0x64000000u, 0x64000000u, 0x64000000u, 0x64000000u};
+    }
+  }
   __builtin_amdgcn_sched_barrier(0);
 
+  // VALU issue is arbitrated by priority, then age: the later waves of a SIMD (w >> 2 = 1, 2, 3) otherwise get the leftover
+  // slots and finish last; static priorities for the later half even that out (tools/gemv_lab)
+  if (wave >= 12) __builtin_amdgcn_s_setprio(2);
+  else if (wave >= 8) __builtin_amdgcn_s_setprio(1);
   uint32_t mlo = kLoNib, mhi = kHiNib, magic = kMagicF16;
   asm volatile("" : "+s"(mlo), "+s"(mhi));               // opaque: (w & m) | magic then selects v_and_or_b32 (one literal each)
   asm volatile("" : "+v"(magic));

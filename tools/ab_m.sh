@@ -1,9 +1,12 @@
 #!/bin/bash
 out=${1:-gpurun_out/ab_m.log}
 : > $out
-for M in 1 2 4 8; do
-  for cfg in "AWQ_RP2=0" "AWQ_RP2=1 AWQ_RP2_D=2 AWQ_RP2_M1=1" "AWQ_RP2=1 AWQ_RP2_D=2 AWQ_RP2_M1=0" "AWQ_RP2=1 AWQ_RP2_D=0 AWQ_RP2_M1=0"; do
+for shape in "4096 11008" "11008 4096" "4096 22016"; do
+set -- $shape
+for M in 1 4 16; do
+  for cfg in "AWQ_RP2=0" "AWQ_RP2=1 AWQ_RP2_D=2" "AWQ_RP2=1 AWQ_RP2_D=0"; do
     echo -n "[$cfg] " >> $out
-    env $cfg tools/kbench rgemm $M 4096 11008 128 16 1600 >> $out 2>&1 || exit 1
+    env $cfg tools/kbench rgemm $M $1 $2 128 16 1600 >> $out 2>&1 || exit 1
   done
+done
 done

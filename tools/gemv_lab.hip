@@ -305,7 +305,7 @@ __global__ __launch_bounds__(W * 64) void lab2_kernel(LabArgs a) {
 //   staging (weights only), 6 full compute without x / zs staging (constant x, zs)  -- timing ablations
 template <int G, int T, int W, int D, int ABL, int NT, int SB>
 __global__ __launch_bounds__(W * 64) void lab3_kernel(LabArgs a) {
-  constexpr int STAMPS = SB & 1, BAR = SB >> 1;     // SB = stamps + 2 * (initial issue rounds separated by workgroup barriers)
+  constexpr int STAMPS = SB & 1, BAR = (SB >> 1) & 7, PRIO = SB >> 4;     // SB = stamps + 2 * (barrier-separated issue rounds) + 16 * priority mode
   extern __shared__ __attribute__((aligned(16))) float red[];
   constexpr int L = G * T;
   constexpr int DD = (D == 0 || D > L) ? L : D;
@@ -365,6 +365,13 @@ __global__ __launch_bounds__(W * 64) void lab3_kernel(LabArgs a) {
   uint32_t mlo = kLoNib, mhi = kHiNib, magic = kMagicF16;
   asm volatile("" : "+s"(mlo), "+s"(mhi));
   asm volatile("" : "+v"(magic));
+  if constexpr (PRIO == 1) {          // later waves (which lose the age-based VALU arbitration) get the higher priority
+    if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(1); else if ((wave >> 2) == 2) __builtin_amdgcn_s_setprio(2); else if ((wave >> 2) == 3) __builtin_amdgcn_s_setprio(3);
+  } else if constexpr (PRIO == 2) {
+    if ((wave >> 2) == 0) __builtin_amdgcn_s_setprio(3); else if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(2); else if ((wave >> 2) == 2) __builtin_amdgcn_s_setprio(1);
+  } else if constexpr (PRIO == 3) {
+    if (wave >= 12) __builtin_amdgcn_s_setprio(2); else if (wave >= 8) __builtin_amdgcn_s_setprio(1);
+  }
   float4_t acc[G];
 #pragma unroll
   for (int c = 0; c < G; ++c) acc[c] = (float4_t){0.f, 0.f, 0.f, 0.f};
@@ -519,6 +526,12 @@ static const Variant kVariants4096[] = {
     V(1, 2, 16, 0, 1, 0, 0, 0, 1),
     V3(3, 2, 16, 0, 0, 1, 0),
     V3(3, 2, 16, 2, 0, 1, 4),
+    V3(3, 2, 16, 2, 0, 1, 20),
+    V3(3, 2, 16, 2, 0, 1, 52),
+    V3(3, 2, 16, 2, 0, 1, 36),
+    V3(3, 2, 16, 0, 0, 1, 16),
+    V3(3, 2, 16, 0, 0, 1, 32),
+    V3(3, 2, 16, 3, 0, 1, 22),
     V3(3, 2, 16, 3, 0, 1, 6),
     V3(3, 2, 16, 3, 0, 1, 2),
     V3(3, 2, 16, 0, 0, 1, 12),
