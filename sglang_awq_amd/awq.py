@@ -141,7 +141,7 @@ class AWQLinearMethod(LinearMethodBase):
             from . import ops
 
             ops.awq_gemm_cache_clear()           # (re)loaded weights: copies the drop-in op made of the old values are stale
-            if self.repack and self.apply_mode == "fused" and layer.scales.dtype == torch.float16:
+            if self.repack and self.apply_mode == "fused" and layer.scales.dtype in (torch.float16, torch.bfloat16):
                 layer.awq_packed = ops.awq_repack(layer.qweight.data, layer.scales.data, layer.qzeros.data)
                 # SGLANG_AWQ_AMD_KEEP_CHECKPOINT=0: a fused-only deployment never reads the checkpoint tensors again (every batch
                 # size runs on the repacked copy); releasing them halves the weight memory (70B at TP = 1: 35 GB).  The

@@ -46,9 +46,10 @@ static int repacked_dispatch(const GemmArgs& a, const void* packed) {
     c.y = (char*)a.y + (size_t)16 * a.N * 2;
     return launch_gemv_repacked(c, packed);
   }
+  if (!repacked_fast(a.K, a.N, a.g, a.dtype)) return launch_gemm_repacked_tiled(a, packed);   // bf16 / g in {32, 64}: the generic tiles from 33 rows on
   const bool aligned = a.ldx % 8 == 0 && (((uintptr_t)a.x) & 15) == 0;
   const int64_t wide_tiles = ((M + 127) / 128) * ((a.N + 255) / 256);
-  if (env_mid != 0 && aligned && M > 96 && wide_tiles <= 64) return launch_gemm_repacked_ksplit(a, packed);
+  if (env_mid != 0 && aligned && M > 96 && wide_tiles <= 64 && repacked_fast(a.K, a.N, a.g, a.dtype)) return launch_gemm_repacked_ksplit(a, packed);
   if (M <= 160) {
     const size_t eb2 = 2;
     for (int64_t m0 = 0; m0 < M; m0 += 32) {
@@ -105,7 +106,7 @@ constexpr size_t kWorkspaceHead = 4096;        // arrival counters of the split-
 
 size_t awq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t group_size, int dtype) {
   if (M <= 0 || K <= 0 || N <= 0) return kWorkspaceHead;
-  if (M >= kRepackOnTheFlyMinM && repacked_supported(K, N, group_size, dtype)) return kWorkspaceHead + repacked_bytes(K, N, group_size);
+  if (M >= kRepackOnTheFlyMinM && repacked_fast(K, N, group_size, dtype)) return kWorkspaceHead + repacked_bytes(K, N, group_size);
   return skinny_workspace_bytes(M, K, N);
 }
 
@@ -138,7 +139,7 @@ int awq_gemm_ex(const void* x, int64_t ldx, const int32_t* qweight, const void* 
     if (!workspace || workspace_bytes < awq_gemm_workspace_bytes(M, K, N, group_size, dtype)) return AWQ_ERR_WORKSPACE;
     return launch_gemm_skinny(a);
   }
-  if (M >= kRepackOnTheFlyMinM && repacked_supported(K, N, group_size, dtype) && workspace && (((uintptr_t)workspace) & 15) == 0 &&
+  if (M >= kRepackOnTheFlyMinM && repacked_fast(K, N, group_size, dtype) && workspace && (((uintptr_t)workspace) & 15) == 0 &&
       workspace_bytes >= kWorkspaceHead + repacked_bytes(K, N, group_size) && a.ldx % 8 == 0 && (((uintptr_t)x) & 15) == 0) {
     void* packed = (char*)workspace + kWorkspaceHead;
     rc = launch_repack(qweight, scales, qzeros, packed, K, N, group_size, dtype, a.stream);

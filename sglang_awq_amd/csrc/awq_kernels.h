@@ -48,9 +48,13 @@ int launch_gemm_skinny(const GemmArgs& a);
 bool tiled_supported(const GemmArgs& a);
 int launch_gemm_tiled(const GemmArgs& a);
 
-// MFMA-fragment-major re-layout + the kernels on it (fp16, K % 128 == 0, g % 128 == 0): decode GEMV (M <= 32 per launch)
+// MFMA-fragment-major re-layout + the kernels on it (fp16 / bf16, K % 128 == 0, g % 128 == 0 or g in {32, 64}): decode GEMV, prefill tiles
 size_t repacked_bytes(int64_t K, int64_t N, int64_t g);
 bool repacked_supported(int64_t K, int64_t N, int64_t g, int dtype);
+// the subset with the tuned kernels (fp16, g % 128 == 0): straight-line GEMV, hand-pipelined prefill, fused decode variants
+bool repacked_fast(int64_t K, int64_t N, int64_t g, int dtype);
+int launch_gemv_repacked_ext(const GemmArgs& a, const void* packed);          // bf16 / small groups, M <= 16 (awq_repacked_ext.hip)
+int launch_gemm_repacked_tiled_ext(const GemmArgs& a, const void* packed);    // bf16 / small groups, large M
 int launch_repack(const int32_t* qweight, const void* scales, const int32_t* qzeros, void* packed, int64_t K, int64_t N, int64_t g,
                   int dtype, hipStream_t stream);
 int launch_gemv_repacked(const GemmArgs& a, const void* packed);

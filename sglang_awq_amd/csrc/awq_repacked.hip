@@ -283,6 +283,7 @@ static void pf_launch(const GemmArgs& a, const u32x4_t* qw_r, const uint32_t* zs
 
 int launch_gemm_repacked_tiled(const GemmArgs& a, const void* packed) {
   if (!repacked_supported(a.K, a.N, a.g, a.dtype) || a.M < 1 || a.ldx % 8 || (((uintptr_t)a.x) & 15)) return AWQ_ERR_BAD_VARIANT;
+  if (!repacked_fast(a.K, a.N, a.g, a.dtype)) return launch_gemm_repacked_tiled_ext(a, packed);     // bf16 / g in {32, 64}
   const int NG = (a.N + 15) / 16;
   const u32x4_t* qw_r = (const u32x4_t*)packed;
   const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
@@ -303,8 +304,12 @@ size_t repacked_bytes(int64_t K, int64_t N, int64_t g) {
 }
 
 bool repacked_supported(int64_t K, int64_t N, int64_t g, int dtype) {
-  return dtype == AWQ_DTYPE_F16 && K % 128 == 0 && g % 128 == 0 && K % g == 0 && N % 8 == 0 && K > 0 && N > 0 &&
-         rp_groups(N) >= 1;
+  return (dtype == AWQ_DTYPE_F16 || dtype == AWQ_DTYPE_BF16) && K > 0 && N > 0 && g > 0 && K % 128 == 0 && (g % 128 == 0 || g == 64 || g == 32) &&
+         K % g == 0 && N % 8 == 0 && rp_groups(N) >= 1;
+}
+
+bool repacked_fast(int64_t K, int64_t N, int64_t g, int dtype) {
+  return dtype == AWQ_DTYPE_F16 && g % 128 == 0 && repacked_supported(K, N, g, dtype);
 }
 
 int launch_repack(const int32_t* qweight, const void* scales, const int32_t* qzeros, void* packed, int64_t K, int64_t N, int64_t g,
@@ -332,6 +337,18 @@ static int rp_env(const char* name, int dflt) { const char* v = getenv(name); re
 
 int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
   if (!repacked_supported(a.K, a.N, a.g, a.dtype) || a.M < 1 || a.M > 16 * kRpMaxMT || a.ldx % 8 || (((uintptr_t)a.x) & 15)) return AWQ_ERR_BAD_VARIANT;
+  if (!repacked_fast(a.K, a.N, a.g, a.dtype)) {           // bf16 / g in {32, 64}: the generic kernel, 16 rows per launch
+    const size_t eb = 2;
+    for (int m0 = 0; m0 < a.M; m0 += 16) {
+      GemmArgs c = a;
+      c.M = a.M - m0 < 16 ? a.M - m0 : 16;
+      c.x = (const char*)a.x + (size_t)m0 * a.ldx * eb;
+      c.y = (char*)a.y + (size_t)m0 * a.N * eb;
+      const int rc = launch_gemv_repacked_ext(c, packed);
+      if (rc) return rc;
+    }
+    return AWQ_OK;
+  }
   const int NG = rp_groups(a.N), KB = a.K / 128;
   const bool two_tiles = a.M > 16;
   const int MT = two_tiles ? 2 : 1;

@@ -19,7 +19,7 @@ static bool fused_go(int G, const GemmArgs& a, const void* packed, int NG, int p
 int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed) {
   const bool norm = a.norm_h != nullptr;
   if (!norm && !a.silu_mul) return launch_gemv_repacked(a, packed);
-  if (!repacked_supported(a.K, a.N, a.g, a.dtype) || a.M < 1 || a.M > 32 || a.ldx % 8) return AWQ_ERR_BAD_VARIANT;
+  if (!repacked_fast(a.K, a.N, a.g, a.dtype) || a.M < 1 || a.M > 32 || a.ldx % 8) return AWQ_ERR_BAD_VARIANT;   // fp16, g % 128 == 0 only
   if (a.M > 16) {                                                            // two row tiles: SiLU-mul epilogue only, 8 waves
     if (norm || !a.silu_mul || a.N % 32 || (((uintptr_t)a.x) & 15)) return AWQ_ERR_BAD_VARIANT;
     const int NG2 = rp_groups(a.N), KB2 = a.K / 128;

@@ -412,7 +412,7 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_ksplit_kernel(con
 }
 
 int launch_gemm_repacked_ksplit(const GemmArgs& a, const void* packed) {
-  if (!repacked_supported(a.K, a.N, a.g, a.dtype) || a.M < 1 || a.ldx % 8 || (((uintptr_t)a.x) & 15)) return AWQ_ERR_BAD_VARIANT;
+  if (!repacked_fast(a.K, a.N, a.g, a.dtype) || a.M < 1 || a.ldx % 8 || (((uintptr_t)a.x) & 15)) return AWQ_ERR_BAD_VARIANT;
   const int NG = rp_groups(a.N);
   const uint32_t* qw_r = (const uint32_t*)packed;
   const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;

@@ -136,7 +136,7 @@ def awq_gemm_cache_info() -> dict:
 def _op_cached_repack(qweight, scales, qzeros, K, N, g):
     """The op's repacked copy of (qweight, scales, qzeros), made on a miss; None if unsupported / disabled / capturing."""
     global _op_cache_bytes
-    if not _OP_CACHE_ENABLED or scales.dtype != torch.float16:
+    if not _OP_CACHE_ENABLED or scales.dtype not in (torch.float16, torch.bfloat16):
         return None
     key = (qweight.device.index, qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(), K, N, g)
     ent = _op_cache.get(key)
@@ -149,7 +149,7 @@ def _op_cached_repack(qweight, scales, qzeros, K, N, g):
         _op_cache_bytes -= packed.numel()
     if torch.cuda.is_current_stream_capturing():
         return None                                   # fill on an eager (warm-up) call only
-    nbytes = _lib.load().awq_repacked_bytes(K, N, g, _lib.DTYPE_F16)
+    nbytes = _lib.load().awq_repacked_bytes(K, N, g, _DTYPE_CODE[scales.dtype])
     if nbytes == 0 or _op_cache_bytes + nbytes > _OP_CACHE_MAX_BYTES:
         return None
     packed = awq_repack(qweight, scales, qzeros)
@@ -305,12 +305,13 @@ def awq_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor
     return packed
 
 
-def check_packed(packed: torch.Tensor, K: int, N: int, group_size: int, dev: torch.device) -> None:
+def check_packed(packed: torch.Tensor, K: int, N: int, group_size: int, dev: torch.device, dtype: torch.dtype = torch.float16) -> None:
     """A repacked buffer is opaque bytes: the kernels index it from (K, N, group_size) alone, so a mismatching buffer would be
     read out of bounds.  Refuse anything but a uint8 tensor of exactly awq_repacked_bytes(K, N, group_size) on `dev`."""
-    need = _lib.load().awq_repacked_bytes(K, N, group_size, _lib.DTYPE_F16)
+    need = _lib.load().awq_repacked_bytes(K, N, group_size, _DTYPE_CODE.get(dtype, -1))
     if need == 0:
-        raise AwqHipError(f"awq repacked layout does not support K={K} N={N} group_size={group_size} (fp16, K % 128 == 0, group_size % 128 == 0)")
+        raise AwqHipError(f"awq repacked layout does not support K={K} N={N} group_size={group_size} {dtype} "
+                          "(fp16 / bf16, K % 128 == 0, group_size a multiple of 128 or 32 / 64)")
     if packed.dtype != torch.uint8 or packed.numel() != need or not packed.is_contiguous() or packed.device != dev:
         raise RuntimeError(f"awq: repacked buffer must be a contiguous uint8 tensor of {need} bytes on {dev} for K={K} N={N} "
                            f"group_size={group_size}, got {packed.dtype} x {packed.numel()} on {packed.device}")
@@ -318,22 +319,23 @@ def check_packed(packed: torch.Tensor, K: int, N: int, group_size: int, dev: tor
 
 def awq_gemm_repacked(input: torch.Tensor, packed: torch.Tensor, K: int, N: int, group_size: int,
                       bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = input @ W (+ bias) from the repacked copy, any M (GEMV passes of 32 rows up to 160 rows, the MFMA-bound
-    tiled kernel beyond), fp16.  Same numerics as awq_gemm / awq_linear."""
-    if input.dim() != 2 or input.shape[1] != K or input.dtype != torch.float16:
-        raise RuntimeError(f"awq_gemm_repacked: input must be fp16 [M, {K}], got {input.dtype} {tuple(input.shape)}")
+    """y = input @ W (+ bias) from the repacked copy, any M, in the dtype of `input` — fp16 or bf16, which must be the dtype of
+    the scales the copy was made from (the copy stores their bits).  Same numerics as awq_gemm / awq_linear."""
+    dt = input.dtype
+    if input.dim() != 2 or input.shape[1] != K or dt not in (torch.float16, torch.bfloat16):
+        raise RuntimeError(f"awq_gemm_repacked: input must be fp16 / bf16 [M, {K}], got {input.dtype} {tuple(input.shape)}")
     if input.stride(1) != 1:
         input = input.contiguous()
-    if bias is not None and (bias.dtype != torch.float16 or bias.shape != (N,) or not bias.is_contiguous()):
-        raise RuntimeError(f"awq_gemm_repacked: bias must be a contiguous fp16 [{N}] tensor")
+    if bias is not None and (bias.dtype != dt or bias.shape != (N,) or not bias.is_contiguous()):
+        raise RuntimeError(f"awq_gemm_repacked: bias must be a contiguous {dt} [{N}] tensor")
     M = input.shape[0]
     ldx = input.stride(0) if M > 1 else max(input.stride(0), K)
     lib = _lib.load()
     dev = input.device
-    check_packed(packed, K, N, group_size, dev)
+    check_packed(packed, K, N, group_size, dev, dt)
     with _on_device(dev):
-        y = torch.empty((M, N), dtype=torch.float16, device=dev)
-        rc = lib.awq_gemm_repacked(_vp(input), ldx, _vp(packed), _vp(bias), _vp(y), M, K, N, group_size, _lib.DTYPE_F16,
+        y = torch.empty((M, N), dtype=dt, device=dev)
+        rc = lib.awq_gemm_repacked(_vp(input), ldx, _vp(packed), _vp(bias), _vp(y), M, K, N, group_size, _DTYPE_CODE[dt],
                                    ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     _lib.check(rc, "awq_gemm_repacked")
     return y

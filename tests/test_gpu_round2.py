@@ -255,3 +255,64 @@ def test_graphed_decoder_refuses_to_leave_the_kv_cache():
     dec.reset(3)
     dec.run(2)
     assert int(dec.pos.max()) == 5
+
+
+@pytest.mark.parametrize("dt,g", [("bf16", 128), ("f16", 64), ("f16", 32), ("bf16", 64), ("bf16", 32), ("bf16", 512)])
+def test_repacked_layout_bf16_and_small_groups_vs_oracle(ops, dt, g):
+    """bf16 and the Triton path's small groups (g in {32, 64}: awq_triton.py:250) on the MFMA-fragment-major
+    layout — awq_repack + awq_gemm_repacked over the decode range (one launch, two 16-row passes), the GEMV-pass range
+    and the tiled kernel, ragged N and K, with and without bias; plus AWQLinearMethod.apply and the drop-in op's cached copy."""
+    from sglang_awq_amd.awq import AWQConfig, AWQLinearMethod
+
+    for (K, N) in [(512, 1056), (1152, 72), (4096, 4096)]:
+        if K % g:
+            continue
+        qw, s, qz = synth.make_awq_weights(K, N, g, dt, "A", seed=K + N + g)
+        dq, ds, dz = _dev(qw, s, qz)
+        packed = ops.awq_repack(dq, ds, dz)
+        assert packed is not None and packed.numel() == ops._lib.load().awq_repacked_bytes(K, N, g, 0)
+        Ms = [1, 5, 16, 17, 32, 100, 300] if K < 4096 else [1, 16, 300]
+        for M in Ms:
+            x = synth.make_activations(M, K, dt, "A", seed=M + K)
+            _, exact = c_oracle.gemm(x, qw, s, qz, want_exact=True)
+            y = ops.awq_gemm_repacked(to_torch(x, DEV), packed, K, N, g)
+            assert_gemm_close(to_np(y), exact, dt, what=f"repacked {dt} g={g} M={M} K={K} N={N}")
+            if M in (1, 100):
+                b = synth.make_bias(N, dt, 3)
+                yb = ops.awq_gemm_repacked(to_torch(x, DEV), packed, K, N, g, to_torch(b, DEV))
+                assert torch.equal(yb, y + to_torch(b, DEV))
+                assert torch.equal(ops.awq_gemm(to_torch(x, DEV), dq, ds, dz, 1), y), "op (cached copy) != awq_gemm_repacked"
+    ops.awq_gemm_cache_clear()
+    # the linear method repacks these too
+    K, N = 1024, 2048
+    qw, s, qz = synth.make_awq_weights(K, N, g, dt, "A", seed=g)
+    method = AWQLinearMethod(AWQConfig(4, g, True))
+    layer = torch.nn.Module()
+    method.create_weights(layer, K, [N], K, N, torch.bfloat16 if dt == "bf16" else torch.float16, weight_loader=None)
+    layer.qweight.data.copy_(to_torch(qw)); layer.qzeros.data.copy_(to_torch(qz)); layer.scales.data.copy_(to_torch(s))
+    layer.to(DEV)
+    method.process_weights_after_loading(layer)
+    assert layer.awq_packed is not None
+    x = synth.make_activations(7, K, dt, "A", seed=1)
+    _, exact = c_oracle.gemm(x, qw, s, qz, want_exact=True)
+    assert_gemm_close(to_np(method.apply(layer, to_torch(x, DEV))), exact, dt, what=f"apply {dt} g={g}")
+
+
+def test_repacked_small_group_one_hot_rows_reproduce_dequantize(ops):
+    """One-hot activations through the repacked kernels select single rows of W: bit-equality with awq_dequantize for g = 32
+    (every k-step its own scale / zero) in fp16 and bf16 — a wrong group index cannot hide behind a tolerance."""
+    K, N, g = 512, 256, 32
+    for dt in ("f16", "bf16"):
+        qw, s, qz = synth.make_awq_weights(K, N, g, dt, "F", seed=17)
+        dq, ds, dz = _dev(qw, s, qz)
+        W = ops.awq_dequantize(dq, ds, dz)
+        packed = ops.awq_repack(dq, ds, dz)
+        rows = [0, 31, 32, 63, 64, 100, 127, 128, 300, 511]
+        x = torch.zeros(len(rows), K, dtype=W.dtype, device=DEV)
+        for i, k in enumerate(rows):
+            x[i, k] = 1.0
+        assert torch.equal(ops.awq_gemm_repacked(x, packed, K, N, g), W[rows]), dt
+        xb = torch.zeros(200, K, dtype=W.dtype, device=DEV)
+        idx = torch.arange(200, device=DEV) * 7 % K
+        xb[torch.arange(200, device=DEV), idx] = 1.0
+        assert torch.equal(ops.awq_gemm_repacked(xb, packed, K, N, g), W[idx]), dt + " tiled"

@@ -179,20 +179,27 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
 def test_repacked_entry_points_refuse_shapes_without_a_layout(lib):
     """awq_gemm_repacked indexes `packed` from (K, N, group_size) alone: shapes the fragment-major layout does not exist for
-    (bf16 / fp32, K % 128, group_size % 128) must come back as AWQ_ERR_BAD_VARIANT before anything is launched."""
+    (fp32, K % 128, group sizes other than 32 / 64 / multiples of 128) must come back as AWQ_ERR_BAD_VARIANT before anything
+    is launched; fp16 and bf16 with g in {32, 64, 128 k} have one (same bytes for both dtypes)."""
     buf = (ctypes.c_char * 8192)()
     p = (ctypes.cast(buf, ctypes.c_void_p).value + 15) & ~15
     vp = ctypes.c_void_p
     assert lib.awq_repacked_bytes(4096, 11008, 128, 0) == 688 * 32 * 1024 + 688 * 32 * 64
-    assert lib.awq_repacked_bytes(4096, 11008, 64, 0) == 0 and lib.awq_repacked_bytes(4096, 11008, 128, 1) == 0
-    assert lib.awq_repacked_bytes(192, 64, 64, 0) == 0
+    assert lib.awq_repacked_bytes(4096, 11008, 128, 1) == lib.awq_repacked_bytes(4096, 11008, 128, 0)
+    assert lib.awq_repacked_bytes(4096, 11008, 64, 0) == 688 * 32 * 1024 + 688 * 64 * 64
+    assert lib.awq_repacked_bytes(4096, 11008, 32, 1) == 688 * 32 * 1024 + 688 * 128 * 64
+    assert lib.awq_repacked_bytes(4096, 11008, 128, 2) == 0 and lib.awq_repacked_bytes(4096, 11008, 16, 0) == 0
+    assert lib.awq_repacked_bytes(192, 64, 64, 0) == 0 and lib.awq_repacked_bytes(4096, 64, 4096 // 3 + 1, 0) == 0
     # K = 192 (not a multiple of 128), group 64: legal AWQ shape, no repacked layout -> -7, for every M route
     for M in (1, 16, 32, 64, 100, 200, 2048):
         assert lib.awq_gemm_repacked(vp(p), 192, vp(p), None, vp(p), M, 192, 64, 64, 0, None) == -7, M
-    assert lib.awq_gemm_repacked(vp(p), 4096, vp(p), None, vp(p), 128, 4096, 4096, 128, 1, None) == -7      # bf16
-    assert lib.awq_gemm_repacked(vp(p), 4096, vp(p), None, vp(p), 128, 4096, 4096, 64, 0, None) == -7       # g = 64
+    assert lib.awq_gemm_repacked(vp(p), 4096, vp(p), None, vp(p), 128, 4096, 4096, 128, 2, None) == -7      # fp32
+    assert lib.awq_gemm_repacked(vp(p), 4096, vp(p), None, vp(p), 128, 4096, 4096, 16, 0, None) == -7       # g = 16
     assert lib.awq_gemm_repacked(None, 4096, vp(p), None, vp(p), 1, 4096, 4096, 128, 0, None) == -1
+    # the fused decode variants exist for fp16 with g % 128 == 0 only
     assert lib.awq_aux_gemv_repacked_fused(vp(p), 192, vp(p), vp(p), 1, 192, 64, 64, 0, None, None, None, None, 0.0, 1, None) == -7
+    assert lib.awq_aux_gemv_repacked_fused(vp(p), 4096, vp(p), vp(p), 1, 4096, 4096, 64, 0, None, None, None, None, 0.0, 1, None) == -7
+    assert lib.awq_aux_gemv_repacked_fused(vp(p), 4096, vp(p), vp(p), 1, 4096, 4096, 128, 1, None, None, None, None, 0.0, 1, None) == -7
 
 
 def test_python_shim_checks_the_repacked_buffer():
@@ -208,5 +215,6 @@ def test_python_shim_checks_the_repacked_buffer():
         ops.check_packed(torch.empty(need // 4, dtype=torch.int32), 4096, 11008, 128, cpu)
     with pytest.raises(RuntimeError):
         ops.check_packed(torch.empty(need, dtype=torch.uint8), 4096, 11008, 256, cpu)     # same K, N, other group size
+    ops.check_packed(torch.empty(688 * 32 * 1024 + 688 * 64 * 64, dtype=torch.uint8), 4096, 11008, 64, cpu, torch.bfloat16)
     with pytest.raises(ops.AwqHipError):
-        ops.check_packed(torch.empty(16, dtype=torch.uint8), 4096, 11008, 64, cpu)        # no layout for g = 64
+        ops.check_packed(torch.empty(16, dtype=torch.uint8), 4096, 11008, 16, cpu)        # no layout for g = 16
