@@ -6,6 +6,8 @@
 //                     repacked from column-interleaved gate / up groups, so both halves of a pair sit in one strip.
 // Same kernel template as the plain operator (awq_repacked_gemv.h); only 16-wave, straight-line, one-row-tile
 // instantiations exist, anything else returns AWQ_ERR_BAD_VARIANT and the caller runs the unfused sequence.
+#include <cstdlib>
+
 #include "../../include/awq_aux.h"
 #include "awq_repacked_gemv.h"
 
@@ -56,13 +58,17 @@ int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed) {
     if ((((uintptr_t)a.norm_h) | ((uintptr_t)a.norm_delta) | ((uintptr_t)a.norm_w) | ((uintptr_t)a.norm_h_out)) & 15) return AWQ_ERR_BAD_VARIANT;
     const int per_lane = (a.M * T * 16 + 63) / 64;                           // chunks of 8 halves per lane of a wave's own columns
     PRO = per_lane <= 1 ? 1 : per_lane <= 2 ? 2 : per_lane <= 4 ? 4 : 0;
-    if (!PRO) return AWQ_ERR_BAD_VARIANT;
   }
   size_t lds = (size_t)W * a.M * 16 * G * sizeof(float);
-  if (!norm) {                                                               // SiLU-mul epilogue only: the restructured kernel when it has an instantiation
-    if (rp2_launch<1>(G, T, a, packed, NG, 2, nwg)) return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+  // the restructured kernel (gemv_rp2_kernel: norm folded through the GEMV, SiLU-mul epilogue) wherever it has an instantiation;
+  // AWQ_RP2_NORM=0: the earlier prologue form (A/B)
+  static const bool env_norm2 = !(getenv("AWQ_RP2_NORM") && atoi(getenv("AWQ_RP2_NORM")) == 0);
+  if (!norm || env_norm2) {
+    const bool ok = norm ? (a.silu_mul ? rp2_launch<1, true>(G, T, a, packed, NG, 2, nwg) : rp2_launch<0, true>(G, T, a, packed, NG, 2, nwg))
+                         : rp2_launch<1, false>(G, T, a, packed, NG, 2, nwg);        // (!norm && !silu_mul went to the plain launcher above)
+    if (ok) return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
   }
-  if (!rp_fits_fused(G, T, PRO, a.silu_mul)) return AWQ_ERR_BAD_VARIANT;
+  if ((norm && !PRO) || !rp_fits_fused(G, T, PRO, a.silu_mul)) return AWQ_ERR_BAD_VARIANT;
   if (norm) lds += (size_t)W * a.M * (T * 128 + 8) * 2 + (size_t)W * PRO * 4 * sizeof(float);
   if (lds > (size_t)kRpMaxLds) return AWQ_ERR_BAD_VARIANT;
   bool launched;

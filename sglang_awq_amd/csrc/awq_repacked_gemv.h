@@ -311,11 +311,20 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
 // sums added in wave order through LDS), so results are bit-identical to it.
 // M1: specialisation for one row (M == 1): no row arithmetic in the staging addresses, A fragments broadcast from row 0,
 // one result element per column; CHS is then a function of (G, T) alone.
-template <int G, int T, int CHS, int D, int EPI, bool M1>
+// NORM: the RMSNorm(+residual) in front of the linear (models/llama.py:277-290), folded through the GEMV's linearity:
+//   y = (rmsnorm(v) * w) W = inv_rms(v) * ((v * w) W),   v = h + delta.
+// A wave stages x' = fp16(v) * w for its own k-blocks (no dependence on other waves, no barrier before the weight loads),
+// adds up its share of sum(v^2) on the side, and the epilogue — which already meets all waves in LDS — multiplies the fp32
+// sums by inv_rms = rsqrt(sum(v^2) / K + eps) before the one rounding to fp16.  Against the eager order
+// fp16(fp16(v * inv) * w) this moves where x is rounded (by at most an fp16 ulp of x per element; the tests restate this
+// order in the oracle and bound the distance to the eager order); workgroup 0 stores v = h + delta (fp16 add, bit-exact).
+// The earlier norm prologue (gemv_repacked_kernel, PRO > 0) needed every workgroup to re-read all of h + delta and one
+// workgroup barrier before its weight loads: +1.6 us at M = 1, +6.5 at M = 8; this form costs two extra staging loads.
+template <int G, int T, int CHS, int D, int EPI, bool M1, bool NORM = false>
 __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restrict__ x, int64_t ldx, const u32x4_t* __restrict__ qw_r,
                                                         const uint32_t* __restrict__ zs_r, const void* __restrict__ bias,
                                                         void* __restrict__ y, int M, int K, int N, int groups, int gmul,
-                                                        int gshift, int NG) {
+                                                        int gshift, int NG, RpFuse fz) {
   constexpr int W = 16;
   constexpr int L = G * T;
   constexpr int DD = (D == 0 || D > L) ? L : D;
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
   // staging chunks (16 B): 16 M T chunks of x (row, 8-half column chunk) and 4 G T chunks of zs words of (c, t).  M == 1:
   // one id space, lanes take ids lane + 64 i (x first, then zs) -> a single load at G = 3, T = 2.  M > 1: CHS loads of x
   // chunks, then one load of the (<= 64) zs chunks — no per-lane select between the two address computations.
-  constexpr int NZ = G * T * 4, CHT = M1 ? CHS : CHS + 1;
+  constexpr int NZ = G * T * 4, CHT = (M1 && !NORM) ? CHS : CHS + 1;
   const int nx = M * T * 16;
   u32x4_t sv[CHT];
   int sdst[CHT];
@@ -347,7 +356,28 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
     src = (const unsigned char*)(zs_r + ((size_t)(cg0 + c) * groups + ((kbz * gmul) >> gshift)) * 16 + part * 4);
     dst = xbytes + ((c * T + t) * 16 + part * 4) * 4;
   };
-  if constexpr (M1) {
+  typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+  h8_t nh[NORM ? CHS : 1], nd[NORM ? CHS : 1], nw[NORM ? CHS : 1];        // NORM: h, delta, w chunks in place of x
+  bool nin[NORM ? CHS : 1];
+  float* const norm_part = (float*)((unsigned char*)(red + (size_t)W * M * 16 * G) + (size_t)W * (xbytes + G * T * 64 + 16));   // [W][M][T], then inv[M]
+  if constexpr (NORM) {
+#pragma unroll
+    for (int i = 0; i < CHS; ++i) {
+      const int id = lane + 64 * i;
+      const int row = id / (T * 16), cc = id - row * (T * 16);
+      nin[i] = id < nx && (kb0 * 128 + cc * 8 < K);
+      const size_t off = nin[i] ? (size_t)row * ldx + (size_t)kb0 * 128 + cc * 8 : 0;
+      nh[i] = *(const h8_t*)(fz.h + off);
+      nd[i] = *(const h8_t*)(fz.delta + off);
+      nw[i] = *(const h8_t*)(fz.w + (nin[i] ? kb0 * 128 + cc * 8 : 0));
+      sdst[i] = id < nx ? (row * XS + cc * 8) * 2 : dump;
+    }
+    const unsigned char* sz;
+    int dz;
+    zs_chunk(lane < NZ ? lane : NZ - 1, sz, dz);
+    sv[CHS] = *(const u32x4_t*)sz;
+    sdst[CHS] = lane < NZ ? dz : dump;
+  } else if constexpr (M1) {
 #pragma unroll
     for (int i = 0; i < CHS; ++i) {
       const int id = lane + 64 * i;
@@ -395,6 +425,25 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
     if (D != 0 && i < 2) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
   }
   __builtin_amdgcn_sched_barrier(0);
+  if constexpr (NORM) {
+#pragma unroll
+    for (int i = 0; i < CHS; ++i) {
+      const int id = lane + 64 * i;
+      const int row = id / (T * 16), cc = id - row * (T * 16);
+      const h8_t v = nh[i] + nd[i];                                      // fp16 add, as the eager h = h + delta
+      if (blockIdx.x == 0 && nin[i]) *(h8_t*)(fz.h_out + (size_t)row * ldx + (size_t)kb0 * 128 + cc * 8) = v;
+      sv[i] = __builtin_bit_cast(u32x4_t, v * nw[i]);                    // x' = v * w (fp16 product); inv_rms comes in the epilogue
+      float ss = 0.f;
+      if (nin[i]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += (float)v[e] * (float)v[e];
+      }
+      // the 16 chunks of one (row, k-block) sit in one aligned group of 16 lanes: segmented sum, the group leader keeps it
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+      if ((lane & 15) == 0 && id < nx) norm_part[((size_t)wave * M + row) * T + (cc >> 4)] = ss;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < CHT; ++i) *(u32x4_t*)(stg + sdst[i]) = sv[i];
   if (kb0 + T > KB) {
@@ -417,7 +466,7 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
   asm volatile("" : "+v"(magic));
   const half2_t c960 = {(half_t)960.f, (half_t)960.f};
   const half2_t sixteenth = {(half_t)0.0625f, (half_t)0.0625f};
-  const half_t* x_lds = (const half_t*)stg + (M1 ? 0 : (size_t)(r < M ? r : M - 1) * XS);
+  const half_t* x_lds = (const half_t*)stg + (M1 ? 0 : (size_t)(r < M ? r : M - 1) * XS);   // (M1: row 0 in either chunk layout)
   const uint32_t* zs_lds = (const uint32_t*)(stg + xbytes) + r;
   float4_t acc[G];
 #pragma unroll
@@ -471,6 +520,16 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
     }
   }
   __syncthreads();
+  float* const inv_rms = norm_part + (size_t)W * M * T;                  // [M]
+  if constexpr (NORM) {
+    if ((int)threadIdx.x < M) {
+      float tot = 0.f;
+      for (int w = 0; w < W; ++w)
+        for (int t = 0; t < T; ++t) tot += norm_part[((size_t)w * M + threadIdx.x) * T + t];      // fixed order
+      inv_rms[threadIdx.x] = __builtin_amdgcn_rsqf(tot / (float)K + fz.eps);
+    }
+    __syncthreads();
+  }
   if constexpr (EPI == 1) {
     // strip = G / 2 (gate, up) pairs of column groups; output column = 16 * (pair index) + r of act[M, N / 2]
     const int SH = 8 * G, I = N / 2;
@@ -486,6 +545,7 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
         gv += red[((size_t)w * M + m) * SW + cgate];
         uv += red[((size_t)w * M + m) * SW + cgate + 16];
       }
+      if constexpr (NORM) { gv *= inv_rms[m]; uv *= inv_rms[m]; }
       const float xg = (float)(half_t)gv;                                // the unfused path rounds gate_up to fp16 first
       ((half_t*)y)[(size_t)m * I + n] = (half_t)(xg / (1.f + __expf(-xg))) * (half_t)uv;
     }
@@ -497,6 +557,7 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
       float v = red[(size_t)m * SW + col];
 #pragma unroll
       for (int w = 1; w < W; ++w) v += red[((size_t)w * M + m) * SW + col];
+      if constexpr (NORM) v *= inv_rms[m];
       store_output<AWQ_DTYPE_F16>(y, (size_t)m * N + n, v, bias, n);
     }
   }
@@ -506,9 +567,12 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
 // (G, T, chunks) combination has no instantiation (caller falls back to gemv_repacked_kernel)
 constexpr bool rp2_fits(int G, int T) { return G >= 1 && G <= kRpMaxG && T >= 1 && T <= 8 && G * T <= 16; }
 inline int rp2_chunks(int M, int G, int T) { (void)G; const int n = (M * T * 16 + 63) / 64; return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : n <= 8 ? 8 : 0; }   // x chunks per lane, M > 1
-inline size_t rp2_lds(int M, int G, int T) { return (size_t)16 * M * 16 * G * sizeof(float) + (size_t)16 * ((size_t)M * (T * 128 + 8) * 2 + (size_t)G * T * 64 + 16); }
+inline size_t rp2_lds(int M, int G, int T, bool norm = false) {
+  return (size_t)16 * M * 16 * G * sizeof(float) + (size_t)16 * ((size_t)M * (T * 128 + 8) * 2 + (size_t)G * T * 64 + 16) +
+         (norm ? ((size_t)16 * M * T + M) * sizeof(float) : 0);
+}
 
-template <int G, int T, int EPI>
+template <int G, int T, int EPI, bool NORM>
 static bool rp2_launch_t(const GemmArgs& a, const void* packed, int NG, int chunks, int depth, int nwg, size_t lds) {
   if constexpr (!rp2_fits(G, T) || (EPI == 1 && (G & 1))) {
     return false;
@@ -519,68 +583,77 @@ static bool rp2_launch_t(const GemmArgs& a, const void* packed, int NG, int chun
     int lg = 0;
     while ((1 << lg) < gk) ++lg;
     const int gshift = 12 + lg, gmul = (int)(((1ll << gshift) + gk - 1) / gk);
-#define RP2_GO(CHS, DEP, ONE)                                                                                                      \
+    const RpFuse fz = {(const half_t*)a.norm_h, (const half_t*)a.norm_delta, (const half_t*)a.norm_w, (half_t*)a.norm_h_out, a.norm_eps};
+#define RP2_GO(CHS, DEP, ONE, NRM)                                                                                                 \
     do {                                                                                                                           \
-      auto kern = gemv_rp2_kernel<G, T, CHS, DEP, EPI, ONE>;                                                                       \
+      auto kern = gemv_rp2_kernel<G, T, CHS, DEP, EPI, ONE, NRM>;                                                                  \
       static unsigned long long opted[2] = {0ull, 0ull};                                                                           \
       if (lds > 64 * 1024 && !opt_in_dynamic_lds((const void*)kern, kRpMaxLds, opted)) return false;                                \
       hipLaunchKernelGGL(kern, dim3(nwg), dim3(1024), lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r, a.bias, a.y, a.M, a.K, \
-                         a.N, a.K / a.g, gmul, gshift, NG);                                                                        \
+                         a.N, a.K / a.g, gmul, gshift, NG, fz);                                                                    \
       return true;                                                                                                                 \
     } while (0)
     static const bool env_m1 = !(getenv("AWQ_RP2_M1") && atoi(getenv("AWQ_RP2_M1")) == 0);   // A/B knob
-    if (a.M == 1 && env_m1) {
-      constexpr int C1 = (T * 16 + G * T * 4 + 63) / 64;          // <= 5 for G T <= 16
-      constexpr int CH1 = C1 <= 1 ? 1 : C1 <= 2 ? 2 : C1 <= 4 ? 4 : 8;
-      if (depth == 0) RP2_GO(CH1, 0, true);
-      RP2_GO(CH1, 2, true);
-    }
-    if (depth == 0) {
-      if (chunks == 1) RP2_GO(1, 0, false);
-      if (chunks == 2) RP2_GO(2, 0, false);
-      if (chunks == 4) RP2_GO(4, 0, false);
-      if (chunks == 8) RP2_GO(8, 0, false);
+    if constexpr (NORM) {                                // x chunk layout of the generic form at every M (chunks = x chunks per lane)
+      if (a.M == 1 && chunks == 1) RP2_GO(1, 2, true, true);
+      if (chunks == 1) RP2_GO(1, 2, false, true);
+      if (chunks == 2) RP2_GO(2, 2, false, true);
+      if (chunks == 4) RP2_GO(4, 2, false, true);
+      if (chunks == 8) RP2_GO(8, 2, false, true);
     } else {
-      if (chunks == 1) RP2_GO(1, 2, false);
-      if (chunks == 2) RP2_GO(2, 2, false);
-      if (chunks == 4) RP2_GO(4, 2, false);
-      if (chunks == 8) RP2_GO(8, 2, false);
+      if (a.M == 1 && env_m1) {
+        constexpr int C1 = (T * 16 + G * T * 4 + 63) / 64;          // <= 5 for G T <= 16
+        constexpr int CH1 = C1 <= 1 ? 1 : C1 <= 2 ? 2 : C1 <= 4 ? 4 : 8;
+        if (depth == 0 && EPI == 0) RP2_GO(CH1, 0, true, false);
+        RP2_GO(CH1, 2, true, false);
+      }
+      if (depth == 0 && EPI == 0) {
+        if (chunks == 1) RP2_GO(1, 0, false, false);
+        if (chunks == 2) RP2_GO(2, 0, false, false);
+        if (chunks == 4) RP2_GO(4, 0, false, false);
+        if (chunks == 8) RP2_GO(8, 0, false, false);
+      } else {
+        if (chunks == 1) RP2_GO(1, 2, false, false);
+        if (chunks == 2) RP2_GO(2, 2, false, false);
+        if (chunks == 4) RP2_GO(4, 2, false, false);
+        if (chunks == 8) RP2_GO(8, 2, false, false);
+      }
     }
 #undef RP2_GO
     return false;
   }
 }
 
-template <int G, int EPI>
+template <int G, int EPI, bool NORM>
 static bool rp2_launch_g(int T, const GemmArgs& a, const void* packed, int NG, int chunks, int depth, int nwg, size_t lds) {
   switch (T) {
-    case 1: return rp2_launch_t<G, 1, EPI>(a, packed, NG, chunks, depth, nwg, lds);
-    case 2: return rp2_launch_t<G, 2, EPI>(a, packed, NG, chunks, depth, nwg, lds);
-    case 3: return rp2_launch_t<G, 3, EPI>(a, packed, NG, chunks, depth, nwg, lds);
-    case 4: return rp2_launch_t<G, 4, EPI>(a, packed, NG, chunks, depth, nwg, lds);
-    case 5: return rp2_launch_t<G, 5, EPI>(a, packed, NG, chunks, depth, nwg, lds);
-    case 6: return rp2_launch_t<G, 6, EPI>(a, packed, NG, chunks, depth, nwg, lds);
-    case 7: return rp2_launch_t<G, 7, EPI>(a, packed, NG, chunks, depth, nwg, lds);
-    case 8: return rp2_launch_t<G, 8, EPI>(a, packed, NG, chunks, depth, nwg, lds);
+    case 1: return rp2_launch_t<G, 1, EPI, NORM>(a, packed, NG, chunks, depth, nwg, lds);
+    case 2: return rp2_launch_t<G, 2, EPI, NORM>(a, packed, NG, chunks, depth, nwg, lds);
+    case 3: return rp2_launch_t<G, 3, EPI, NORM>(a, packed, NG, chunks, depth, nwg, lds);
+    case 4: return rp2_launch_t<G, 4, EPI, NORM>(a, packed, NG, chunks, depth, nwg, lds);
+    case 5: return rp2_launch_t<G, 5, EPI, NORM>(a, packed, NG, chunks, depth, nwg, lds);
+    case 6: return rp2_launch_t<G, 6, EPI, NORM>(a, packed, NG, chunks, depth, nwg, lds);
+    case 7: return rp2_launch_t<G, 7, EPI, NORM>(a, packed, NG, chunks, depth, nwg, lds);
+    case 8: return rp2_launch_t<G, 8, EPI, NORM>(a, packed, NG, chunks, depth, nwg, lds);
     default: return false;
   }
 }
 
 // launches gemv_rp2_kernel if an instantiation exists for (G, T = per-wave k-blocks at 16 waves, M); false = nothing enqueued
-template <int EPI>
+template <int EPI, bool NORM = false>
 static bool rp2_launch(int G, int T, const GemmArgs& a, const void* packed, int NG, int depth, int nwg) {
   const int chunks = rp2_chunks(a.M, G, T);
-  const size_t lds = rp2_lds(a.M, G, T);
+  const size_t lds = rp2_lds(a.M, G, T, NORM);
   if (!chunks || a.M > 16 || lds > (size_t)kRpMaxLds || a.K / 128 >= 4096 || a.g / 128 >= 4096) return false;
   switch (G) {
-    case 1: return rp2_launch_g<1, EPI>(T, a, packed, NG, chunks, depth, nwg, lds);
-    case 2: return rp2_launch_g<2, EPI>(T, a, packed, NG, chunks, depth, nwg, lds);
-    case 3: return rp2_launch_g<3, EPI>(T, a, packed, NG, chunks, depth, nwg, lds);
-    case 4: return rp2_launch_g<4, EPI>(T, a, packed, NG, chunks, depth, nwg, lds);
-    case 5: return rp2_launch_g<5, EPI>(T, a, packed, NG, chunks, depth, nwg, lds);
-    case 6: return rp2_launch_g<6, EPI>(T, a, packed, NG, chunks, depth, nwg, lds);
-    case 7: return rp2_launch_g<7, EPI>(T, a, packed, NG, chunks, depth, nwg, lds);
-    case 8: return rp2_launch_g<8, EPI>(T, a, packed, NG, chunks, depth, nwg, lds);
+    case 1: return rp2_launch_g<1, EPI, NORM>(T, a, packed, NG, chunks, depth, nwg, lds);
+    case 2: return rp2_launch_g<2, EPI, NORM>(T, a, packed, NG, chunks, depth, nwg, lds);
+    case 3: return rp2_launch_g<3, EPI, NORM>(T, a, packed, NG, chunks, depth, nwg, lds);
+    case 4: return rp2_launch_g<4, EPI, NORM>(T, a, packed, NG, chunks, depth, nwg, lds);
+    case 5: return rp2_launch_g<5, EPI, NORM>(T, a, packed, NG, chunks, depth, nwg, lds);
+    case 6: return rp2_launch_g<6, EPI, NORM>(T, a, packed, NG, chunks, depth, nwg, lds);
+    case 7: return rp2_launch_g<7, EPI, NORM>(T, a, packed, NG, chunks, depth, nwg, lds);
+    case 8: return rp2_launch_g<8, EPI, NORM>(T, a, packed, NG, chunks, depth, nwg, lds);
     default: return false;
   }
 }

@@ -166,8 +166,10 @@ def test_gemm_repacked_vs_oracle(ops, M):
         assert_gemm_close(y, exact, "f16", what=f"repacked M={M} K={K} N={N} g={g}")
         yb = ops.awq_gemm_repacked(to_torch(x, DEV), packed, K, N, g, to_torch(b, DEV))
         assert torch.equal(yb, to_torch(y, DEV) + to_torch(b, DEV))
-    assert ops.awq_repack(*_dev(*synth.make_awq_weights(256, 64, 32, "f16", "A", 1))) is None        # g = 32: not supported
-    assert ops.awq_repack(*_dev(*synth.make_awq_weights(256, 64, 128, "bf16", "A", 1))) is None      # bf16: not supported
+    assert ops.awq_repack(*_dev(*synth.make_awq_weights(256, 64, 16, "f16", "A", 1))) is None         # g = 16: no layout
+    assert ops.awq_repack(*_dev(*synth.make_awq_weights(192, 64, 64, "f16", "A", 1))) is None         # K % 128 != 0: no layout
+    assert ops.awq_repack(*_dev(*synth.make_awq_weights(256, 64, 128, "f32", "A", 1))) is None        # fp32: no layout
+    # (g in {32, 64} and bf16 have one since round 2: tests/test_gpu_round2.py)
 
 
 @pytest.mark.parametrize("M", [1, 3, 8])
@@ -236,13 +238,24 @@ def test_gemv_repacked_fused_vs_oracle(ops, M):
         assert r is not None, f"no fused kernel for M={M} K={K} N={N}"
         y, h_out = r
         assert np.array_equal(to_np(h_out), v)
+        # Two orders of the same arithmetic exist: the eager one, x = fp16(fp16(v * inv) * w) before the GEMM (what the separate
+        # ops and the older prologue kernel compute), and the folded one of gemv_rp2_kernel<NORM>, y = inv * ((v * w) W) with
+        # inv applied to the fp32 sums.  Whichever kernel ran must match ITS order to the GEMM bound, and both stay close.
         _, exact = c_oracle.gemm(xn, qw, s, qz, want_exact=True)
+        xw = v * w                                                                  # fp16 product
+        _, exact_f = c_oracle.gemm(xw, qw, s, qz, want_exact=True)
+        exact_f = exact_f * inv
         got = to_np(y).astype(np.float64)
-        err = np.abs(got - exact)
-        assert np.all(err <= 0.5 * ulp(exact, "f16") + 2e-3), f"norm-fused M={M} K={K} N={N}: worst {err.max():.3e}"
-        # x itself can differ from the numpy rebuild by an fp16 ulp in a few elements (v_rsq_f32 vs exact 1 / sqrt), so
-        # "equals the correctly rounded sum of the rebuilt x" holds for most outputs, not 98 % as for a given x
-        assert float((got != exact.astype(np.float16).astype(np.float64)).mean()) < 0.15
+        err_e, err_f = np.abs(got - exact), np.abs(got - exact_f)
+        ok_e = np.all(err_e <= 0.5 * ulp(exact, "f16") + 2e-3)
+        ok_f = np.all(err_f <= 0.5 * ulp(exact_f, "f16") + 1e-3)
+        assert ok_e or ok_f, f"norm-fused M={M} K={K} N={N}: worst vs eager order {err_e.max():.3e}, vs folded order {err_f.max():.3e}"
+        ref = exact_f if ok_f else exact
+        # v_rsq_f32 vs exact 1 / sqrt moves a few results across a rounding boundary: most, not 98 %, are the correctly rounded sum
+        assert float((got != ref.astype(np.float16).astype(np.float64)).mean()) < 0.15
+        # the two orders round x at different points: per element <= ~1.5 fp16 ulps of x apart, a random walk over K terms
+        row_scale = np.sqrt((exact ** 2).mean(-1, keepdims=True))                   # (an output near 0 is a cancellation of terms this size)
+        assert np.all(err_e <= 0.5 * ulp(exact, "f16") + 1e-4 * np.sqrt(K) * (1.0 + row_scale)), "folded and eager orders drifted apart"
         # 2. SiLU-mul epilogue only (x given)
         x = synth.make_activations(M, K, "f16", "A", seed=M + K + 6)
         r = aux_ops.gemv_repacked_fused(packed_il, K, N, g, x=to_torch(x, DEV), silu_mul=True)
@@ -257,11 +270,14 @@ def test_gemv_repacked_fused_vs_oracle(ops, M):
         # 3. both
         r = aux_ops.gemv_repacked_fused(packed_il, K, N, g, norm=(dev[0], dev[1], dev[2], eps), silu_mul=True)
         assert r is not None
-        _, exact = c_oracle.gemm(xn, qw, s, qz, want_exact=True)
-        want = silu_mul(exact).astype(np.float64)
+        _, exact = c_oracle.gemm(xn, qw, s, qz, want_exact=True)                     # eager order again (step 2 used a given x)
+        want_e = silu_mul(exact).astype(np.float64)
+        want_f = silu_mul(exact_f).astype(np.float64)
         got = to_np(r[0]).astype(np.float64)
-        tol = 2.0 * ulp(want, "f16") + 4e-3 * (1.0 + np.abs(exact[:, N // 2:]))
-        assert np.all(np.abs(got - want) <= tol), f"norm+silu M={M} K={K} N={N}: worst {np.abs(got - want).max():.3e}"
+        tol = 2.0 * ulp(want_e, "f16") + 4e-3 * (1.0 + np.abs(exact[:, N // 2:]))
+        d_e, d_f = np.abs(got - want_e), np.abs(got - want_f)
+        assert np.all(d_e <= tol) or np.all(d_f <= tol), f"norm+silu M={M} K={K} N={N}: worst {d_e.max():.3e} / {d_f.max():.3e}"
+        assert np.all(d_e <= tol + 2e-4 * np.sqrt(K) * (1.0 + row_scale) * (1.0 + np.abs(exact[:, N // 2:]) + np.abs(exact[:, :N // 2])))
         assert np.array_equal(to_np(r[1]), v)
 
 

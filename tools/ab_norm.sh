@@ -1,0 +1,12 @@
+#!/bin/bash
+out=${1:-gpurun_out/ab_norm.log}
+: > $out
+for shape in "4096 12288 1" "4096 22016 3"; do
+set -- $shape
+for M in 1 2 4 8; do
+  for cfg in "AWQ_RP2_NORM=0" "AWQ_RP2_NORM=1"; do
+    echo -n "[$cfg] " >> $out
+    env $cfg tools/kbench rgemm $M $1 $2 128 16 1600 1 $3 >> $out 2>&1 || echo "(no kernel)" >> $out
+  done
+done
+done
