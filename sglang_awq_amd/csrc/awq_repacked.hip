@@ -387,8 +387,11 @@ int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
   // AWQ_RP2_D=0 (every load up front) are A/B knobs for tools/kbench.
   // Ring depth: two loads in flight per wave (4096 x 11008: 6.73 -> 6.37 us at M = 1 against every load up front in
   // tools/gemv_lab; kbench at M = 4: 7.03 vs 7.14, 11008 x 4096 at M = 4: 8.36 vs 8.48).  AWQ_RP2_D=0: everything up front.
+  // It also wins on small, largely cache-resident matrices as long as every one of the 16 waves has a k-block (KB >= 16):
+  // 4096 x 4096 4.39 -> 4.07 us, 8192 x 1280 5.88 -> 4.72; with fewer k-blocks (1024 x 8192: 3.60 vs 3.81) the 8-wave form stays.
   static const int env_rp2 = rp_env("AWQ_RP2", 1), env_d = rp_env("AWQ_RP2_D", -1);
-  if (env_rp2 && W == 16 && !two_tiles && nt && env_t != 0) {
+  const bool rp2_small = !big && !rounds && env_waves == 0 && env_nt < 0 && KB >= 16;
+  if (env_rp2 && !two_tiles && env_t != 0 && ((W == 16 && nt) || rp2_small)) {
     const int depth = env_d >= 0 ? env_d : 2;
     if (rp2_launch<0>(G, (KB + 15) / 16, a, packed, NG, depth, nwg)) return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
   }

@@ -88,7 +88,7 @@ class LlamaDecoderLayer(torch.nn.Module):
         self.register_buffer("k_cache", torch.zeros(max_batch, self.num_kv_heads, max_seq, self.head_dim, dtype=dtype), persistent=False)
         self.register_buffer("v_cache", torch.zeros(max_batch, self.num_kv_heads, max_seq, self.head_dim, dtype=dtype), persistent=False)
 
-    FUSE_NORM_MAX_BATCH = 4
+    FUSE_NORM_MAX_BATCH = 16
     attn_splits = 1            # workgroups per (sequence, head) in the decode attention; GraphedDecoder sets it from batch / context
 
     @staticmethod
@@ -118,8 +118,10 @@ class LlamaDecoderLayer(torch.nn.Module):
 
         B = h.shape[0]
         eps = self.cfg.rms_norm_eps
-        # measured on 4096-wide rows: the norm prologue adds 1.4 / 1.6 / 3.9 / 6.5 us at 1 / 2 / 4 / 8 rows (every workgroup
-        # re-reads h + delta) against 4.7 us for the separate launch; the SiLU-mul epilogue is free at every batch size
+        # the norm is folded through the GEMV (gemv_rp2_kernel<NORM>: x' = (h + delta) * w staged per wave, inv_rms applied to
+        # the fp32 sums in the epilogue): 4096 x 12288 at 1 / 2 / 4 / 8 rows 7.4 / 8.3 / 8.7 / 10.1 us against 8.9 / 9.2 / 11.0 /
+        # 14.5 for the earlier prologue form and ~4.7 us for a separate norm launch; the SiLU-mul epilogue is free at every batch
+        # size.  Beyond 16 rows the GEMV runs two row tiles per fragment and the norm is its own launch.
         fuse_norm = B <= self.FUSE_NORM_MAX_BATCH
         qkv = None
         packed = getattr(self.qkv_proj, "awq_packed", None)
