@@ -305,216 +305,6 @@ __global__ __launch_bounds__(kSkWaves * 64, 1) void gemm_skinny_kernel(
 }
 
 // =================================================================================================
-// Loader / consumer variant ("DMA"): the k-loop above has one weakness the stamps make visible — a
-// wave issues in order, so while it is blocked pushing its loads against memory back-pressure it
-// cannot dequantise what has already landed.  Here the roles are split inside the workgroup:
-//   wave 4 (loader)      streams the workgroup's k-steps into an LDS ring with global_load_lds
-//                        (16 B per lane, no VGPR destination), counted vmcnt, publishes `ready`
-//   waves 0-3 (consumers) one per SIMD: wait for their slot, ds_read_b128 it back (lane-linear, so
-//                        every lane gets exactly the bytes "its" lane loaded), dequantise, MFMA
-// Slot = one k-step: 8 rows x 1 KiB of packed words + 1 KiB scales + 1 KiB zero words (x4 copies) +
-// 1 KiB of x fragments = 11 KiB; 12 slots = 132 KiB of the CU's 160 KiB LDS.  Progress words live in
-// LDS: `ready` (slots landed, written by the loader after its counted s_waitcnt) and one `taken[c]`
-// per consumer (slots whose bytes are in its registers), so a slot is refilled only after its reader
-// is done with it.  Every spin is bounded; a timeout raises an error word in the workspace.
-constexpr int kDmaPairs = 4;                      // consumer c (wave c) is fed by loader c (wave 4 + c)
-constexpr int kDmaSlotsPerPair = 3;
-constexpr int kDmaSlots = kDmaPairs * kDmaSlotsPerPair;      // 12 x 11 KiB = 132 KiB
-constexpr int kDmaSlotBytes = 11 * 1024;
-// (11 DMA instructions per k-step: 8 weight rows + scales + zeros + x)
-constexpr int kDmaConsumers = kDmaPairs;
-constexpr int kDmaThreads = 2 * kDmaPairs * 64;
-constexpr int kDmaCtrlOffset = kDmaSlots * kDmaSlotBytes;   // ready[4], taken[4], ticket
-constexpr unsigned kDmaSpinLimit = 1u << 22;
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gbl_void_t;
-
-__device__ __forceinline__ void glds16(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)l, 16, 0, 0);
-}
-
-// The loaders' own LDS accesses go through inline asm: hipcc treats an LDS-DMA in flight as a pending LDS
-// write that any LDS access might alias and would drain vmcnt(0) in front of every progress-word update.
-__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(unsigned long)(lds_void_t*)p; }
-__device__ __forceinline__ void lds_store_u32_raw(unsigned addr, unsigned v) {
-  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ unsigned lds_load_u32_raw(unsigned addr) {
-  unsigned v;
-  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-  return v;
-}
-
-template <int DT, int ABL = 0>
-__global__ __launch_bounds__(kDmaThreads, 2) void gemm_skinny_dma_kernel(
-    const uint16_t* __restrict__ x, int64_t ldx, const uint32_t* __restrict__ qw, const uint16_t* __restrict__ scales,
-    const uint32_t* __restrict__ qz, const void* __restrict__ bias, void* __restrict__ y, float* __restrict__ slabs,
-    unsigned* __restrict__ counters, int M, int K, int C, int g, int n_ct, int S, int steps_per_wg) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  float* red = (float*)lds;                       // reduction scratch aliases the ring once it is drained
-  // control words sit behind whichever is larger, the ring or the reduction scratch that later aliases it
-  const int red_bytes = kDmaConsumers * M * kSkRowStride * (int)sizeof(float);
-  unsigned* ctrl = (unsigned*)(lds + (red_bytes > kDmaCtrlOffset ? red_bytes : kDmaCtrlOffset));
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int q = lane >> 4, r = lane & 15;
-  const int ct = blockIdx.x % n_ct;
-  const int ks = blockIdx.x / n_ct;
-  const int N = C * 8;
-  unsigned long long* dbg = (unsigned long long*)((char*)counters + (48u << 20));
-  AWQ_STAMP(0);
-
-  const int k_first = ks * steps_per_wg;
-  int n = K / 32 - k_first;
-  if (n > steps_per_wg) n = steps_per_wg;
-  if (n < 0) n = 0;
-  const int pair = wave & (kDmaPairs - 1);
-  const int n_mine = (n - pair + kDmaPairs - 1) / kDmaPairs;        // k-steps pair, pair + 4, ... of this workgroup
-
-  if (threadIdx.x < 16) ctrl[threadIdx.x] = 0;
-  __syncthreads();
-
-  float4_t acc[4][8];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[c][e] = (float4_t){0.f, 0.f, 0.f, 0.f};
-
-  if (wave >= kDmaPairs) {
-    // ------------------------------------------------------------------------------- loader `pair`
-    const int chunk4 = (ct * 16 + r) * 4 < C ? (ct * 16 + r) * 4 : C - 4;            // clamped (ragged last tile)
-    const int sc_col = ct * 512 + lane * 8 < N ? ct * 512 + lane * 8 : N - 8;
-    const int xr = r < M ? r : M - 1;
-    const unsigned ready_addr = lds_addr_of(ctrl + pair);
-    const unsigned taken_addr = lds_addr_of(ctrl + kDmaPairs + pair);
-    auto issue = [&](int t) {                                      // this pair's t-th k-step -> its slot t % 3
-      const int i = pair + kDmaPairs * t;
-      unsigned char* slot = lds + ((t % kDmaSlotsPerPair) * kDmaPairs + pair) * kDmaSlotBytes;
-      const int k0 = (k_first + i) * 32 + 8 * q;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) glds16(qw + (size_t)(k0 + j) * C + chunk4, slot + j * 1024);
-      const int grp = ((k_first + i) * 32) / g;
-      glds16(scales + (size_t)grp * N + sc_col, slot + 8192);
-      glds16(qz + (size_t)grp * C + chunk4, slot + 9216);
-      glds16(x + (size_t)xr * ldx + k0, slot + 10240);
-    };
-    int done = 0;
-    const int pro = n_mine < kDmaSlotsPerPair ? n_mine : kDmaSlotsPerPair;
-    for (int t = 0; t < pro; ++t) issue(t);
-    for (int t = kDmaSlotsPerPair; t < n_mine; ++t) {
-      asm volatile("s_waitcnt vmcnt(22)" ::: "memory");            // (3 - 1) x 11: this pair's oldest k-step has landed
-      lds_store_u32_raw(ready_addr, (unsigned)++done);
-      // slot reuse: k-step t - 3 must be in the consumer's registers before its slot is refilled
-      const unsigned need = (unsigned)(t - kDmaSlotsPerPair + 1);
-      unsigned spins = 0;
-      while (lds_load_u32_raw(taken_addr) < need) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > kDmaSpinLimit) break;                        // bounded: a stuck consumer shows up as wrong results, not a hang
-      }
-      issue(t);
-    }
-    if (pro > 2) { asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); lds_store_u32_raw(ready_addr, (unsigned)++done); }
-    if (pro > 1) { asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); lds_store_u32_raw(ready_addr, (unsigned)++done); }
-    if (pro > 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_store_u32_raw(ready_addr, (unsigned)++done); }
-  } else {
-    // ------------------------------------------------------------------------------- consumer `pair`
-    for (int t = 0; t < n_mine; ++t) {
-      unsigned spins = 0;
-      while (__hip_atomic_load(&ctrl[pair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= (unsigned)t) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > kDmaSpinLimit) { if (lane == 0) counters[1023] = 0xDEAD0002u; break; }
-      }
-      asm volatile("" ::: "memory");
-      const unsigned char* slot = lds + ((t % kDmaSlotsPerPair) * kDmaPairs + pair) * kDmaSlotBytes;
-      KStep b;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) b.R[j] = *(const u32x4_t*)(slot + j * 1024 + lane * 16);
-#pragma unroll
-      for (int w = 0; w < 4; ++w) b.SC[w] = *(const u32x4_t*)(slot + 8192 + (4 * r + w) * 16);
-      b.ZW = *(const u32x4_t*)(slot + 9216 + lane * 16);
-      b.XA = *(const u32x4_t*)(slot + 10240 + lane * 16);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the slot's bytes are in registers: hand it back
-      if (lane == 0) __hip_atomic_store(&ctrl[kDmaPairs + pair], (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      compute_kstep<DT, 0>(b, acc);
-    }
-  }
-  AWQ_STAMP(3);
-  __syncthreads();          // ring fully consumed (and every DMA retired): its memory becomes the reduction scratch
-
-  if (wave < kDmaConsumers) {
-    float* my_red = red + (size_t)wave * M * kSkRowStride;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = 4 * q + i;
-        if (m < M) {
-          float4_t* dst = (float4_t*)(my_red + (size_t)m * kSkRowStride + r * 36 + 8 * c);
-          dst[0] = (float4_t){acc[c][0][i], acc[c][1][i], acc[c][2][i], acc[c][3][i]};
-          dst[1] = (float4_t){acc[c][4][i], acc[c][5][i], acc[c][6][i], acc[c][7][i]};
-        }
-      }
-  }
-  __syncthreads();
-  AWQ_STAMP(4);
-
-  const int Npad = n_ct * 512;
-  const int nvec = M * 128;
-  const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(slabs, 0, (int)((size_t)S * M * Npad * sizeof(float)), 0x00020000);
-  for (int v = threadIdx.x; v < nvec; v += kDmaThreads) {
-    const int m = v >> 7, nl = (v & 127) * 4;
-    const int off = m * kSkRowStride + (nl >> 5) * 36 + (nl & 31);
-    float4_t a4 = *(const float4_t*)(red + off);
-#pragma unroll
-    for (int w = 1; w < kDmaConsumers; ++w) a4 += *(const float4_t*)(red + (size_t)w * M * kSkRowStride + off);
-    const int nn = ct * 512 + nl;
-    if (S == 1 || ABL == 1) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (nn + e < N) store_output<DT>(y, (size_t)m * N + nn + e, a4[e], bias, nn + e);
-    } else {
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, a4), slab_rsrc,
-                                             (unsigned)((((size_t)ks * M + m) * Npad + nn) * sizeof(float)), 0, 16);
-    }
-  }
-  AWQ_STAMP(5);
-  if (S == 1 || ABL == 1) return;
-
-  // same write-through / ticket / sc1-load hand-off as gemm_skinny_kernel
-  unsigned* ticket_word = ctrl + 2 * kDmaPairs;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0)
-    *ticket_word = __hip_atomic_fetch_add(&counters[ct], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  AWQ_STAMP(6);
-  if (*ticket_word != (unsigned)(S - 1)) return;
-  if (threadIdx.x == 0)
-    __hip_atomic_store(&counters[ct], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned slab_stride_b = (unsigned)((size_t)M * Npad * sizeof(float));
-  for (int v = threadIdx.x; v < nvec; v += kDmaThreads) {
-    const int m = v >> 7, nl = (v & 127) * 4;
-    const int nn = ct * 512 + nl;
-    if (nn >= N) continue;
-    const unsigned base = (unsigned)(((size_t)m * Npad + nn) * sizeof(float));
-    float4_t a4 = {0.f, 0.f, 0.f, 0.f};
-    int sidx = 0;
-    for (; sidx + 8 <= S; sidx += 8) {
-      u32x4_t t[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = __builtin_amdgcn_raw_buffer_load_b128(slab_rsrc, base + (unsigned)(sidx + u) * slab_stride_b, 0, 16);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a4 += __builtin_bit_cast(float4_t, t[u]);
-    }
-    for (; sidx < S; ++sidx) a4 += __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(slab_rsrc, base + (unsigned)sidx * slab_stride_b, 0, 16));
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (nn + e < N) store_output<DT>(y, (size_t)m * N + nn + e, a4[e], bias, nn + e);
-  }
-  AWQ_STAMP(7);
-}
-
 // ------------------------------------------------------------------------------------------ host
 struct SkinnyPlan {
   int S, n_ct, steps_per_wave;
@@ -584,49 +374,10 @@ static void launch_one(const GemmArgs& a, const SkinnyPlan& p) {
   }
 }
 
-template <int DT, int ABL>
-static void launch_dma(const GemmArgs& a, int n_ct, int S, int steps_per_wg, size_t lds_bytes) {
-  const int C = a.N / 8;
-  dim3 grid(n_ct * S), block(kDmaThreads);
-  unsigned* counters = (unsigned*)a.workspace;
-  float* slabs = (float*)((char*)a.workspace + kSkCounterBytes);
-  (void)hipFuncSetAttribute((const void*)gemm_skinny_dma_kernel<DT, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL((gemm_skinny_dma_kernel<DT, ABL>), grid, block, lds_bytes, a.stream, (const uint16_t*)a.x, a.ldx,
-                     (const uint32_t*)a.qweight, (const uint16_t*)a.scales, (const uint32_t*)a.qzeros, a.bias, a.y, slabs,
-                     counters, a.M, a.K, C, a.g, n_ct, S, steps_per_wg);
-}
-
-// loader / consumer variant: one workgroup per CU, any number of k-steps per workgroup (LDS ring)
-static int launch_gemm_skinny_dma(const GemmArgs& a) {
-  const int n_ct = (a.N + 511) / 512;
-  const int ksteps = a.K / 32;
-  int S = (int)((a.tune >> 8) & 0xFF);
-  if (S <= 0) S = kNumCUs / n_ct > 0 ? kNumCUs / n_ct : 1;
-  if (S > ksteps) S = ksteps;
-  const size_t slab_row = (size_t)a.M * n_ct * 512 * sizeof(float);
-  while (S > 1 && (size_t)S * slab_row > a.workspace_bytes - kSkCounterBytes) --S;
-  const int steps_per_wg = (ksteps + S - 1) / S;
-  S = (ksteps + steps_per_wg - 1) / steps_per_wg;
-  size_t red_bytes = (size_t)kDmaConsumers * a.M * kSkRowStride * sizeof(float);
-  size_t lds_bytes = (size_t)kDmaCtrlOffset + 64;
-  if (red_bytes > lds_bytes - 64) lds_bytes = red_bytes + 64;      // control words sit behind the larger of the two
-  if (lds_bytes > 160 * 1024) return AWQ_ERR_BAD_VARIANT;
-  const int abl = (int)((a.tune >> 16) & 7);
-  if (a.dtype == AWQ_DTYPE_F16) {
-    if (abl == 1) launch_dma<AWQ_DTYPE_F16, 1>(a, n_ct, S, steps_per_wg, lds_bytes);
-    else if (abl == 3) { if (a.workspace_bytes < (60u << 20)) return AWQ_ERR_WORKSPACE; launch_dma<AWQ_DTYPE_F16, 3>(a, n_ct, S, steps_per_wg, lds_bytes); }
-    else launch_dma<AWQ_DTYPE_F16, 0>(a, n_ct, S, steps_per_wg, lds_bytes);
-  } else {
-    launch_dma<AWQ_DTYPE_BF16, 0>(a, n_ct, S, steps_per_wg, lds_bytes);
-  }
-  return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
-}
-
 int launch_gemm_skinny(const GemmArgs& a) {
   if (!skinny_supported(a)) return AWQ_ERR_BAD_VARIANT;
   if (a.workspace == nullptr || a.workspace_bytes < kSkCounterBytes) return AWQ_ERR_WORKSPACE;
   if (((uintptr_t)a.workspace) & 15) return AWQ_ERR_MISALIGNED;
-  if (a.tune & 0x100000) return launch_gemm_skinny_dma(a);
   const SkinnyPlan p = skinny_plan(a.M, a.K, a.N, a.workspace_bytes - kSkCounterBytes, a.tune);
   if (p.lds_bytes > 160 * 1024) return AWQ_ERR_BAD_VARIANT;
   const int abl = (int)((a.tune >> 16) & 7);

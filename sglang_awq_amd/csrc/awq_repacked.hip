@@ -19,9 +19,9 @@
 //                               fp16(1024 + zero).  Columns >= N are padded with scale 0.
 // A workgroup owns G consecutive column groups (a strip of 16 G columns) for ALL of K; its 16 (or 8) waves take
 // consecutive k-block ranges and are summed in fixed order through LDS; y is written directly.
-// Kernels: awq_repacked_gemv.h (decode GEMV template), awq_repacked_fused.hip (its fused variants),
-// awq_repacked_prefill.hip (hand-pipelined prefill GEMM); this file: re-layout, launch heuristics, the
-// compiler-scheduled prefill tiles kept for A/B.
+// Kernels: awq_repacked_gemv.h (decode GEMV templates), awq_repacked_fused.hip (its fused variants),
+// awq_repacked_prefill.hip (hand-pipelined prefill GEMM), awq_repacked_ext.hip (bf16 / small groups); this file: re-layout
+// and launch heuristics.
 #include <cstdlib>
 
 #include "awq_repacked_gemv.h"
@@ -125,174 +125,14 @@ __global__ __launch_bounds__(256) void repack_zs_kernel(const uint32_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------ prefill GEMM
-// Large M on the repacked layout, compiler-scheduled tiles — kept for A/B (AWQ_PF_SHAPE = 14 / 22 / 42); the
-// default is the hand-pipelined form of the <1, 4> decomposition in awq_repacked_prefill.hip.
-// The B operand never touches LDS: every wave streams the fragment-major dwords of its own 64 columns straight
-// into registers, dequantises each dword into one MFMA B fragment (13 VALU ops, no transposes) and reuses it for
-// MI row tiles.  Only x goes through LDS: BMt x 128 halves per K step, double-buffered, 16-byte chunks
-// XOR-swizzled so the 16 rows of a fragment read hit 16 different bank groups; one barrier per K step;
-// XCD-aware tile order.
-
-// MFMA with the accumulator tied in place in the AGPR file.  With the builtin, hipcc picks a different destination
-// than srcC for most of the 128 MFMAs of a K step and repairs that with ~150 v_accvgpr copies per step; the tied
-// "+a" operand leaves it no choice.  (The MFMA results are first read long after the loop; see the s_nop there.)
-__device__ __forceinline__ void mfma_inplace(float4_t& acc, const u32x4_t& a, const u32x4_t& b) {
-  asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-}
-
-__device__ __forceinline__ int pf_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }   // [rows][128 halves]
-
-// <WM, WN> waves along M / N; wave tile = (16 MI) x 64 with MI = 8 (4 waves) or 4 (8 waves); workgroup tile BMt x BNt:
-//   <2,2> 256 x 128 (4 waves)   <4,2> 256 x 128 (8 waves, 2 per SIMD)   <1,4> 128 x 256 (4 waves, half the x traffic per CU)
-#ifndef PF_OCC
-#define PF_OCC 1
-#endif
-template <int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64, PF_OCC) void gemm_repacked_tiled_kernel(const uint16_t* __restrict__ x, int64_t ldx,
-                                                                      const u32x4_t* __restrict__ qw_r, const uint32_t* __restrict__ zs_r,
-                                                                      const void* __restrict__ bias, void* __restrict__ y, int M, int K,
-                                                                      int N, int g, int NG, int nbx, int nby) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char As[];      // 2 x 64 KiB
-  constexpr int MI = WM * WN == 8 ? 4 : 8;         // 16 x 16 row tiles per wave
-  constexpr int BMt = WM * MI * 16, BNt = WN * 64;
-  constexpr int NT_ = WM * WN * 64;                // threads
-  constexpr int AL = BMt * 16 / NT_;               // x-tile chunks (16 B) per thread
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int q = lane >> 4, r = lane & 15;
-  const int KB = K / 128, groups = K / g;
-
-  const int nwg = nbx * nby, bid = blockIdx.x;
-  const int xcd = bid & 7, qd = nwg >> 3, rem = nwg & 7;
-  const int logical = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (bid >> 3);
-  const int bm = (logical / nbx) * BMt;
-  const int bn = (logical % nbx) * BNt;
-
-  int cg[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = (bn + wn * 64) / 16 + j;
-    cg[j] = c < NG ? c : NG - 1;                       // clamped: columns >= N are never stored
-  }
-
-  u32x4_t w_cur[4], w_nxt[4];
-  uint32_t zs_cur[4], zs_nxt[4];
-
-  // the next x tile is staged in two halves (registers -> LDS), each half's loads in flight for half a K step:
-  // 16 staging registers instead of 32 keep the non-accumulator values inside the VGPR file (hipcc otherwise
-  // shuttles accumulators through AGPR copies: 144 v_accvgpr moves per K step)
-  constexpr int AH = AL / 2;
-  u32x4_t a_half[AH];
-  auto load_a = [&](int kb, int half) {
-#pragma unroll
-    for (int i = 0; i < AH; ++i) {
-      const int c = tid + NT_ * (half * AH + i);
-      const int row = c >> 4, chunk = c & 15;
-      const int m = bm + row < M ? bm + row : M - 1;
-      a_half[i] = *(const u32x4_t*)(x + (size_t)m * ldx + kb * 128 + chunk * 8);
-    }
-  };
-  auto store_a = [&](int buf, int half) {
-#pragma unroll
-    for (int i = 0; i < AH; ++i) {
-      const int c = tid + NT_ * (half * AH + i);
-      *(u32x4_t*)(As + buf * (BMt * 256) + pf_off(c >> 4, c & 15)) = a_half[i];
-    }
-  };
-  auto load_b = [&](u32x4_t (&w)[4], uint32_t (&zs)[4], int kb) {
-    const int grp = (kb * 128) / g;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      w[j] = qw_r[((size_t)cg[j] * KB + kb) * 64 + lane];
-      zs[j] = zs_r[((size_t)cg[j] * groups + grp) * 16 + r];
-    }
-  };
-
-  float4_t acc[MI][4];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[mi][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-
-  load_a(0, 0);
-  load_b(w_cur, zs_cur, 0);
-  store_a(0, 0);
-  load_a(0, 1);
-  store_a(0, 1);
-  __syncthreads();
-
-  const half2_t c960 = {(half_t)960.f, (half_t)960.f};
-  for (int kb = 0; kb < KB; ++kb) {
-    const int nxt = kb + 1 < KB ? kb + 1 : kb;         // clamped, unconditional prefetch (no branch between load and use)
-    load_a(nxt, 0);
-    load_b(w_nxt, zs_nxt, nxt);
-    __builtin_amdgcn_sched_barrier(0);                 // or hipcc sinks these loads to the end of the body, right in front of their use
-    const unsigned char* Ab = As + (kb & 1) * (BMt * 256);
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      if (d == 2) {                                    // first half lands in the other buffer (nobody reads it before the barrier); second half requested
-        store_a((kb + 1) & 1, 0);
-        load_a(nxt, 1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      u32x4_t af[MI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) af[mi] = *(const u32x4_t*)(Ab + pf_off(wm * (MI * 16) + mi * 16 + r, d * 4 + q));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const half2_t s2 = as_h2(pack_lo16(zs_cur[j], zs_cur[j]));
-        const half2_t z1024 = as_h2(pack_hi16(zs_cur[j], zs_cur[j]));
-        const u32x4_t frag = rp_dequant(w_cur[j][d], z1024, z1024 - c960, s2);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) mfma_inplace(acc[mi][j], af[mi], frag);
-      }
-    }
-    store_a((kb + 1) & 1, 1);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { w_cur[j] = w_nxt[j]; zs_cur[j] = zs_nxt[j]; }
-    __syncthreads();
-  }
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results must have left the pipe before the (compiler-scheduled) reads below
-
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = bm + wm * (MI * 16) + mi * 16 + 4 * q + i;
-      if (m < M) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int n = bn + wn * 64 + j * 16 + r;
-          if (n < N) store_output<AWQ_DTYPE_F16>(y, (size_t)m * N + n, acc[mi][j][i], bias, n);
-        }
-      }
-    }
-}
-
-template <int WM, int WN>
-static void pf_launch(const GemmArgs& a, const u32x4_t* qw_r, const uint32_t* zs_r, int NG) {
-  constexpr int MI = WM * WN == 8 ? 4 : 8;
-  constexpr int BMt = WM * MI * 16, BNt = WN * 64;
-  const int nbx = (a.N + BNt - 1) / BNt, nby = (a.M + BMt - 1) / BMt;
-  const size_t lds = 2 * BMt * 256;
-  static unsigned long long opted[2] = {0ull, 0ull};
-  if (!opt_in_dynamic_lds((const void*)gemm_repacked_tiled_kernel<WM, WN>, (int)lds, opted)) return;
-  hipLaunchKernelGGL((gemm_repacked_tiled_kernel<WM, WN>), dim3(nbx * nby), dim3(WM * WN * 64), lds, a.stream, (const uint16_t*)a.x, a.ldx,
-                     qw_r, zs_r, a.bias, a.y, a.M, a.K, a.N, a.g, NG, nbx, nby);
-}
-
+// Large M on the repacked layout: the hand-pipelined 128 x 256 kernel (awq_repacked_prefill.hip) for fp16 with g % 128 == 0,
+// the compiler-scheduled form of the same decomposition for bf16 / small groups (awq_repacked_ext.hip).  The compiler-scheduled
+// fp16 tiles this file used to carry for A/B (<2,2> 256 x 128: 665 TFLOP/s, <4,2> 8 waves: the same, <1,4> 128 x 256: 730
+// against 890-960 for the pipelined kernel at 2048 x 4096 x 11008) were removed after round 1; DESIGN.md §5.4 keeps the numbers.
 int launch_gemm_repacked_tiled(const GemmArgs& a, const void* packed) {
   if (!repacked_supported(a.K, a.N, a.g, a.dtype) || a.M < 1 || a.ldx % 8 || (((uintptr_t)a.x) & 15)) return AWQ_ERR_BAD_VARIANT;
   if (!repacked_fast(a.K, a.N, a.g, a.dtype)) return launch_gemm_repacked_tiled_ext(a, packed);     // bf16 / g in {32, 64}
-  const int NG = (a.N + 15) / 16;
-  const u32x4_t* qw_r = (const u32x4_t*)packed;
-  const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
-  static const int env_shape = getenv("AWQ_PF_SHAPE") ? atoi(getenv("AWQ_PF_SHAPE")) : 0;       // A/B knob: 22, 42, 14 = compiler-scheduled tiles
-  if (env_shape == 0) return launch_gemm_repacked_pipelined(a, packed);
-  if (env_shape == 22) pf_launch<2, 2>(a, qw_r, zs_r, NG);
-  else if (env_shape == 42) pf_launch<4, 2>(a, qw_r, zs_r, NG);
-  else pf_launch<1, 4>(a, qw_r, zs_r, NG);
-  return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+  return launch_gemm_repacked_pipelined(a, packed);
 }
 
 // ------------------------------------------------------------------------------------------ host

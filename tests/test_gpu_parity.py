@@ -135,19 +135,6 @@ def test_gemm_skinny_vs_oracle(ops, dt, M):
         assert_gemm_close(y, exact, dt, what=f"skinny M={M} K={K} N={N} g={g} tune={tune} {dt}")
 
 
-@pytest.mark.parametrize("dt", ["f16", "bf16"])
-@pytest.mark.parametrize("M", [1, 3, 8, 16])
-def test_gemm_skinny_loader_consumer_vs_oracle(ops, dt, M):
-    """Loader / consumer (LDS-DMA ring) form of the decode kernel, tune bit 20: few and many k-steps per
-    workgroup (S = 1 at K = 4096 puts 128 k-steps through the 12-slot ring: slot reuse), ragged last column
-    tile, every group size."""
-    DMA = 1 << 20
-    for (K, N, g, S) in [(256, 512, 128, 0), (512, 1056, 128, 1), (1024, 96, 64, 3), (384, 544, 32, 0),
-                         (4096, 1024, 128, 1), (4096, 512, 4096, 2), (2048, 1536, 128, 0), (1056 * 2, 1024, 32, 5)]:
-        y, exact, _ = _gemm_case(ops, M, K, N, g, dt, "A", seed=M * 77 + K + N, variant=_lib.GEMM_SKINNY, tune=DMA | (S << 8))
-        assert_gemm_close(y, exact, dt, what=f"dma M={M} K={K} N={N} g={g} S={S} {dt}")
-
-
 @pytest.mark.parametrize("M", [1, 2, 5, 8, 16, 17, 32])
 def test_gemm_repacked_vs_oracle(ops, M):
     """MFMA-fragment-major re-layout + its decode kernel: column counts that are not a multiple
