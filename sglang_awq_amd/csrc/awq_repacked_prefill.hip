@@ -14,6 +14,7 @@
 //     k-block's scales / zeros ride in the same slots; the one barrier per k-block sits inside its last k-step so the
 //     next block's first fragments are fetched behind it in the MFMA shadow.
 // Numerics are those of rp_dequant (same operations in the same order per element).
+#include <cstdlib>
 #include <type_traits>
 
 #include "awq_repacked_gemv.h"
@@ -63,13 +64,19 @@ __device__ __forceinline__ ZsU zs_unpack(uint32_t zs) {
 #ifndef PF_ABL
 #define PF_ABL 0            // diagnostic builds only (timing ablations; results are wrong): 1 no dequant stages, 2 no LDS fragment reads in the loop, 4 no x-tile loads / LDS writes, 8 no barrier
 #endif
-constexpr int kPfBM = 128, kPfBN = 256, kPfThreads = 256;
+constexpr int kPfBM = 128, kPfThreads = 256;
 
+// NJ = column groups (16 columns) per wave: 4 -> 128 x 256 tiles, 3 -> 128 x 192 tiles (three quarters of the time per tile).
+// A launch covers the column groups [cg_base, cg_base + ng_region) of the matrix; the host cuts N into a region of 256-wide
+// tiles that fills whole rounds of the 256 CUs and a remainder of 192-wide tiles, so that 2048 x 11008 costs 2 + 0.75 rounds
+// instead of the 3 that 688 equal tiles pay for 2.69 (launch_gemm_repacked_pipelined).
+template <int NJ>
 __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(const uint16_t* __restrict__ x, int64_t ldx,
                                                                                 const u32x4_t* __restrict__ qw_r,
                                                                                 const uint32_t* __restrict__ zs_r,
                                                                                 const void* __restrict__ bias, void* __restrict__ y, int M,
-                                                                                int K, int N, int g, int NG, int nbx, int nby) {
+                                                                                int K, int N, int g, int NG, int nbx, int nby, int cg_base,
+                                                                                int ng_region) {
   extern __shared__ __attribute__((aligned(16))) unsigned char As[];      // 2 x 32 KiB
   constexpr int MI = 8, AL = 8;                     // row tiles per wave; x-tile chunks (16 B) per thread
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
@@ -80,19 +87,20 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
   const int xcd = bid & 7, qd = nwg >> 3, rem = nwg & 7;
   const int logical = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (bid >> 3);
   const int bm = (logical / nbx) * kPfBM;
-  const int bn = (logical % nbx) * kPfBN;
+  const int cg_tile = cg_base + (logical % nbx) * (4 * NJ) + wn * NJ;       // this wave's first column group
+  const int cg_end = cg_base + ng_region < NG ? cg_base + ng_region : NG;
 
-  int cg[4];
+  int cg[NJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = (bn + wn * 64) / 16 + j;
-    cg[j] = c < NG ? c : NG - 1;                       // clamped: columns >= N are never stored
+  for (int j = 0; j < NJ; ++j) {
+    const int c = cg_tile + j;
+    cg[j] = c < cg_end ? c : cg_end - 1;               // clamped: groups outside the region are never stored
   }
 
   u32x4_t a_st[AL];
-  u32x4_t w_cur[4], w_nxt[4];
-  uint32_t zs_nxt[4];
-  ZsU zu[4], zu_nxt[4];
+  u32x4_t w_cur[NJ], w_nxt[NJ];
+  uint32_t zs_nxt[NJ];
+  ZsU zu[NJ], zu_nxt[NJ];
 
   const uint16_t* xrow[AL];                            // this thread's AL rows / chunks of the x tile, k-block 0
 #pragma unroll
@@ -110,20 +118,20 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
     const int c = tid + kPfThreads * i;
     *(u32x4_t*)(As + buf * (kPfBM * 256) + pfp_off(c >> 4, c & 15)) = a_st[i];
   };
-  auto load_b = [&](u32x4_t (&w)[4], uint32_t (&zs)[4], int kb) {
+  auto load_b = [&](u32x4_t (&w)[NJ], uint32_t (&zs)[NJ], int kb) {
     const int grp = (kb * 128) / g;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       w[j] = qw_r[((size_t)cg[j] * KB + kb) * 64 + lane];
       zs[j] = zs_r[((size_t)cg[j] * groups + grp) * 16 + r];
     }
   };
 
-  float4_t acc[MI][4];
+  float4_t acc[MI][NJ];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[mi][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[mi][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
   // prologue: x tile 0 into LDS, k-block 0's weights / scales in registers, its first fragment dequantised
   load_a(0);
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
 #pragma unroll
   for (int i = 0; i < AL; ++i) store_a1(0, i);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) zu[j] = zs_unpack(zs_nxt[j]);
+  for (int j = 0; j < NJ; ++j) zu[j] = zs_unpack(zs_nxt[j]);
   u32x4_t frag = rp_dequant(w_cur[0][0], zu[0].z1024, zu[0].z64, zu[0].s2);
   load_a(KB > 1 ? 1 : 0);                              // tile 1 travels while block 0 computes
   __syncthreads();
@@ -155,11 +163,11 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         // the fragment after (d, j): (d, j + 1), then (d + 1, 0), then k-block kb + 1's (0, 0)
         DqPipe p;
         ZsU zn;
-        if (j < 3) { p.w = w_cur[j + 1][d]; zn = zu[j + 1]; }
+        if (j < NJ - 1) { p.w = w_cur[j + 1][d]; zn = zu[j + 1]; }
         else if (d < 3) { p.w = w_cur[0][d + 1]; zn = zu[0]; }
         else { uint32_t w0 = w_nxt[0][0]; pin_here(w0); p.w = w0; zn = zu_nxt[0]; }
 #pragma unroll
@@ -180,13 +188,22 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
           // next x tile -> the other buffer, one 1 KiB write every fourth MFMA (eight in a row from all four waves
           // collide with the fragment reads), then the tile after it is requested at once: the 16 workgroups of a
           // row of tiles ask for the same fresh lines together, so they take about a k-block to arrive
-          if (!(PF_ABL & 4) && ((d == 1 && j >= 2) || (d == 2 && j <= 1)) && (mi & 3) == 0)
-            store_a1(nbuf, ((d - 1) * 4 + j - 2) * 2 + (mi >> 2));
-          if (!(PF_ABL & 4) && d == 2 && j == 2 && mi == 0) load_a(nx2);
-          if (d == 2 && j == 3 && mi == 7) { pin_here(zs_nxt[0]); zu_nxt[0] = zs_unpack(zs_nxt[0]); }
+          if constexpr (NJ == 4) {
+            if (!(PF_ABL & 4) && ((d == 1 && j >= 2) || (d == 2 && j <= 1)) && (mi & 3) == 0)
+              store_a1(nbuf, ((d - 1) * 4 + j - 2) * 2 + (mi >> 2));
+            if (!(PF_ABL & 4) && d == 2 && j == 2 && mi == 0) load_a(nx2);
+            if (d == 2 && j == 3 && mi == 7) { pin_here(zs_nxt[0]); zu_nxt[0] = zs_unpack(zs_nxt[0]); }
+          } else {
+            // three fragments per k-step: the eight writes ride in (d, j) = (1, 2), (2, 0), (2, 2) behind MFMAs 0, 3, 6 (the j = 1
+            // slots carry the fragment reads), the next tile is requested behind the last of them
+            const int slot = (d == 1 && j == 2) ? 0 : (d == 2 && j == 0) ? 1 : (d == 2 && j == 2) ? 2 : -1;     // (compile-time after unrolling)
+            if (!(PF_ABL & 4) && slot >= 0 && mi % 3 == 0 && slot * 3 + mi / 3 < AL) store_a1(nbuf, slot * 3 + mi / 3);
+            if (!(PF_ABL & 4) && d == 2 && j == 2 && mi == 7) load_a(nx2);
+            if (d == 2 && j == 1 && mi == 7) { pin_here(zs_nxt[0]); zu_nxt[0] = zs_unpack(zs_nxt[0]); }
+          }
           if (!(PF_ABL & 8) && d == 3 && j == 0 && mi == 0) __syncthreads();
           if (!(PF_ABL & 2) && d == 3 && j == 1) af_n[mi] = *(const u32x4_t*)(An + pfp_off(mi * 16 + r, q));    // next k-block's first fragments
-          if (d == 3 && j < 3 && mi == 7) { pin_here(zs_nxt[j + 1]); zu_nxt[j + 1] = zs_unpack(zs_nxt[j + 1]); }
+          if (d == 3 && j < NJ - 1 && mi == 7) { pin_here(zs_nxt[j + 1]); zu_nxt[j + 1] = zs_unpack(zs_nxt[j + 1]); }
           __builtin_amdgcn_sched_barrier(0);
         }
         frag = p.f;
@@ -197,7 +214,7 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
       }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { w_cur[j] = w_nxt[j]; zu[j] = zu_nxt[j]; }
+    for (int j = 0; j < NJ; ++j) { w_cur[j] = w_nxt[j]; zu[j] = zu_nxt[j]; }
   }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results must have left the pipe before the (compiler-scheduled) reads below
 
@@ -208,25 +225,51 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
       const int m = bm + mi * 16 + 4 * q + i;
       if (m < M) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int n = bn + wn * 64 + j * 16 + r;
-          if (n < N) store_output<AWQ_DTYPE_F16>(y, (size_t)m * N + n, acc[mi][j][i], bias, n);
+        for (int j = 0; j < NJ; ++j) {
+          const int n = (cg_tile + j) * 16 + r;
+          if (cg_tile + j < cg_end && n < N) store_output<AWQ_DTYPE_F16>(y, (size_t)m * N + n, acc[mi][j][i], bias, n);
         }
       }
     }
+}
+
+template <int NJ>
+static int pf_launch_region(const GemmArgs& a, const u32x4_t* qw_r, const uint32_t* zs_r, int NG, int cg_base, int ng_region) {
+  const int nbx = (ng_region + 4 * NJ - 1) / (4 * NJ), nby = (a.M + kPfBM - 1) / kPfBM;
+  const size_t lds = 2 * kPfBM * 256;
+  static unsigned long long opted[2] = {0ull, 0ull};
+  if (!opt_in_dynamic_lds((const void*)gemm_repacked_pipelined_kernel<NJ>, (int)lds, opted)) return AWQ_ERR_LAUNCH;
+  hipLaunchKernelGGL(gemm_repacked_pipelined_kernel<NJ>, dim3(nbx * nby), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r,
+                     zs_r, a.bias, a.y, a.M, a.K, a.N, a.g, NG, nbx, nby, cg_base, ng_region);
+  return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
 int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed) {
   const int NG = rp_groups(a.N);
   const u32x4_t* qw_r = (const u32x4_t*)packed;
   const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
-  const int nbx = (a.N + kPfBN - 1) / kPfBN, nby = (a.M + kPfBM - 1) / kPfBM;
-  const size_t lds = 2 * kPfBM * 256;
-  static unsigned long long opted[2] = {0ull, 0ull};
-  if (!opt_in_dynamic_lds((const void*)gemm_repacked_pipelined_kernel, (int)lds, opted)) return AWQ_ERR_LAUNCH;
-  hipLaunchKernelGGL(gemm_repacked_pipelined_kernel, dim3(nbx * nby), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r,
-                     a.bias, a.y, a.M, a.K, a.N, a.g, NG, nbx, nby);
-  return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+  // Tile quantisation: nA column tiles of 256 (16 groups) + the remaining groups in tiles of 192 (12 groups, 0.75 of the time).
+  // Cost in rounds of the 256 CUs: ceil(tiles_A / 256) + 0.75 ceil(tiles_B / 256) (+ a little for the second launch); the
+  // smallest wins, ties go to fewer launches / wider tiles.  2048 x 11008: 32 x 16 = 512 wide tiles (2 rounds) + 15 x 16 = 240
+  // narrow ones (0.75) instead of 688 wide ones (3 rounds).  AWQ_PF_SPLIT=0 keeps the single launch (A/B).
+  static const bool env_split = !(getenv("AWQ_PF_SPLIT") && atoi(getenv("AWQ_PF_SPLIT")) == 0);
+  const int nby = (a.M + kPfBM - 1) / kPfBM, nA_max = (NG + 15) / 16;
+  int best_nA = nA_max;
+  double best = 1e30;
+  for (int nA = nA_max; nA >= 0 && env_split; --nA) {
+    const int rest = NG - 16 * nA > 0 ? NG - 16 * nA : 0;
+    const int nB = (rest + 11) / 12;
+    if (nA == 0 && nB == 0) continue;
+    const double cost = (double)((nA * nby + 255) / 256) + 0.75 * (double)((nB * nby + 255) / 256) + (nA > 0 && nB > 0 ? 0.02 : 0.0);
+    if (cost < best - 1e-9) { best = cost; best_nA = nA; }
+  }
+  const int gA = best_nA * 16 < NG ? best_nA * 16 : NG;
+  if (gA > 0) {
+    const int rc = pf_launch_region<4>(a, qw_r, zs_r, NG, 0, gA);
+    if (rc) return rc;
+  }
+  if (gA < NG) return pf_launch_region<3>(a, qw_r, zs_r, NG, gA, NG - gA);
+  return AWQ_OK;
 }
 
 
