@@ -314,8 +314,8 @@ def main():
             graphs[k].replay()
             n -= k
 
-    for i in range(min(sets, 4)):
-        step(i)                        # eager warm-up: workspace allocation, RCCL communicator setup
+    for i in range(int(os.environ.get("BENCH_EAGER_PASSES", "1")) * sets):
+        step(i)                        # eager set-up pass over every weight set: workspace allocation, RCCL communicator, page tables
     sync()
     if use_graph:
         try:

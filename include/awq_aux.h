@@ -47,6 +47,19 @@ int awq_aux_gemv_repacked_fused(const void* x, int64_t ldx, const void* packed, 
                                 int64_t group_size, int dtype, const void* norm_h, const void* norm_delta, const void* norm_w,
                                 void* norm_h_out, float norm_eps, int silu_mul, void* stream);
 
+/* AWQ-MoE decode step (the reference's AWQMoEMethod, python/sglang/srt/layers/quantization/awq.py:661-852, runs
+ * NVIDIA Marlin MoE kernels; on ROCm it falls back to moe_wna16's Triton path).  `slots` independent one-row GEMVs in ONE launch:
+ * slot s multiplies activation row s / x_div of x (row stride ldx) with the repacked weight of expert expert_ids[s] —
+ * `packed_experts` holds the experts' awq_repack() outputs back to back, expert_stride_bytes apart (>= awq_repacked_bytes,
+ * multiple of 16) — and writes output row s of y [slots, N] (or [slots, N / 2] with silu_mul = 1: SiLU(gate) * up, experts
+ * repacked from gate / up column-interleaved tensors as for awq_aux_gemv_repacked_fused).  slot_scale (may be NULL): the fp32 sum
+ * of slot s is multiplied by slot_scale[s] before its one rounding — the routed weight, applied where the reference's fused MoE
+ * kernel applies it (mul_routed_weight).  fp16, group_size % 128 == 0; AWQ_ERR_BAD_VARIANT otherwise.  expert_ids are not
+ * range-checked on the device: the caller guarantees 0 <= id < number of experts. */
+int awq_aux_moe_gemv(const void* x, int64_t ldx, int x_div, const void* packed_experts, int64_t expert_stride_bytes,
+                     const int32_t* expert_ids, const float* slot_scale, void* y, int64_t slots, int64_t K, int64_t N,
+                     int64_t group_size, int dtype, int silu_mul, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,12 @@ struct GemmArgs {
   void* norm_h_out = nullptr;        // norm_h + norm_delta, [M, K] with row stride ldx (must not alias norm_h)
   float norm_eps = 0.f;
   int silu_mul = 0;                  // 1: column groups alternate gate / up; y = silu(gate) * up, [M, N / 2]
+  // AWQ-MoE decode (awq_aux_moe_gemv): `moe_slots` (token, expert) pairs, one grid row each; see RpFuse in awq_repacked_gemv.h
+  const int* moe_expert_ids = nullptr;
+  const float* moe_slot_scale = nullptr;
+  int64_t moe_expert_stride = 0;     // bytes between the repacked weights of consecutive experts
+  int moe_x_div = 1;                 // activation row of slot s = s / moe_x_div
+  int moe_slots = 0;
 };
 
 int launch_dequantize(const int32_t* qweight, const void* scales, const int32_t* qzeros, void* out, int64_t K,
@@ -59,6 +65,7 @@ int launch_repack(const int32_t* qweight, const void* scales, const int32_t* qze
                   int dtype, hipStream_t stream);
 int launch_gemv_repacked(const GemmArgs& a, const void* packed);
 int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed);   // norm prologue and / or SiLU-mul epilogue (awq_repacked_fused.hip)
+int launch_gemv_repacked_moe(const GemmArgs& a, const void* packed);     // expert-indirect M = 1 GEMVs, one grid row per (token, expert) slot
 int launch_gemm_repacked_tiled(const GemmArgs& a, const void* packed);   // any M, MFMA-bound prefill shapes
 int launch_gemm_repacked_ksplit(const GemmArgs& a, const void* packed);      // 128 x 64 tiles, K split inside the workgroup (middle M)
 int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed);   // its hand-pipelined 128 x 256 form (awq_repacked_prefill.hip)

@@ -86,7 +86,41 @@ int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed) {
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
+// AWQ-MoE decode: `moe_slots` independent M = 1 GEMVs in one launch, grid row s on the repacked weight of expert
+// moe_expert_ids[s] (gemv_rp2_kernel's expert indirection).  fp16, g % 128 == 0, >= 16 k-blocks.
+int launch_gemv_repacked_moe(const GemmArgs& a, const void* packed) {
+  if (!repacked_fast(a.K, a.N, a.g, a.dtype) || a.M != 1 || a.moe_slots < 1 || a.moe_slots > 65535 || !a.moe_expert_ids || a.moe_x_div < 1 ||
+      a.ldx % 8 || (((uintptr_t)a.x) & 15) || (a.moe_expert_stride & 15))
+    return AWQ_ERR_BAD_VARIANT;
+  if (a.silu_mul && a.N % 32) return AWQ_ERR_BAD_VARIANT;
+  const int NG = rp_groups(a.N), KB = a.K / 128;
+  int G = (NG + 255) / 256;
+  if (a.silu_mul && (G & 1)) ++G;
+  if (G > kRpMaxG || G > NG) return AWQ_ERR_BAD_VARIANT;
+  const int nwg = (NG + G - 1) / G, T = (KB + 15) / 16;
+  const bool ok = a.silu_mul ? rp2_launch<1, false>(G, T, a, packed, NG, 2, nwg) : rp2_launch<0, false>(G, T, a, packed, NG, 2, nwg);
+  if (!ok) return AWQ_ERR_BAD_VARIANT;
+  return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
+
 }  // namespace awq
+
+extern "C" int awq_aux_moe_gemv(const void* x, int64_t ldx, int x_div, const void* packed_experts, int64_t expert_stride_bytes,
+                                const int32_t* expert_ids, const float* slot_scale, void* y, int64_t slots, int64_t K, int64_t N,
+                                int64_t group_size, int dtype, int silu_mul, void* stream) {
+  if (!x || !packed_experts || !expert_ids || !y) return AWQ_ERR_NULL_POINTER;
+  if (K <= 0 || N <= 0 || group_size <= 0 || N % 8 || K % group_size || slots <= 0 || ldx < K || x_div < 1) return AWQ_ERR_BAD_SHAPE;
+  if ((((uintptr_t)packed_experts) & 15) || (((uintptr_t)y) & 1)) return AWQ_ERR_MISALIGNED;
+  awq::GemmArgs a;
+  a.x = x; a.ldx = ldx; a.qweight = nullptr; a.scales = nullptr; a.qzeros = nullptr; a.bias = nullptr; a.y = y;
+  a.workspace = nullptr; a.workspace_bytes = 0;
+  a.M = 1; a.K = (int)K; a.N = (int)N; a.g = (int)group_size; a.dtype = dtype; a.tune = 0;
+  a.stream = (hipStream_t)stream;
+  a.silu_mul = silu_mul;
+  a.moe_expert_ids = expert_ids; a.moe_slot_scale = slot_scale; a.moe_expert_stride = expert_stride_bytes; a.moe_x_div = x_div;
+  a.moe_slots = (int)slots;
+  return awq::launch_gemv_repacked_moe(a, packed_experts);
+}
 
 extern "C" int awq_aux_gemv_repacked_fused(const void* x, int64_t ldx, const void* packed, void* y, int64_t M, int64_t K, int64_t N,
                                            int64_t group_size, int dtype, const void* norm_h, const void* norm_delta,

@@ -87,6 +87,14 @@ struct RpFuse {
   const half_t* w;
   half_t* h_out;
   float eps;
+  // Expert indirection (AWQ-MoE decode, awq_aux_moe_gemv; gemv_rp2_kernel only): when expert_ids != nullptr the grid's y
+  // dimension runs over (token, expert-slot) pairs; slot s uses the packed weight of expert expert_ids[s] (expert_stride
+  // bytes apart), activation row s / x_div, output row s, and its fp32 sums are multiplied by slot_scale[s] (if given)
+  // before the one rounding (the routed weight, applied where the reference's fused MoE applies it).
+  const int* expert_ids;
+  const float* slot_scale;
+  long long expert_stride;
+  int x_div;
 };
 
 // T = k-blocks per wave when it is small enough to issue every load up front (straight-line code, exact
@@ -338,6 +346,16 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
   if (cg0 + G > NG) cg0 = NG - G;                        // last strip overlaps its neighbour (same values written twice)
   const int kb0 = wave * T;
   if constexpr (M1) M = 1;
+  float slot_scale = 1.f;
+  if (fz.expert_ids != nullptr) {                        // AWQ-MoE: one (token, expert) pair per grid row (wave-uniform)
+    const int slot = blockIdx.y;
+    const long long eoff = (long long)fz.expert_ids[slot] * fz.expert_stride;
+    qw_r = (const u32x4_t*)((const unsigned char*)qw_r + eoff);
+    zs_r = (const uint32_t*)((const unsigned char*)zs_r + eoff);
+    x += (size_t)(slot / fz.x_div) * ldx;
+    y = (unsigned char*)y + (size_t)slot * (EPI == 1 ? N / 2 : N) * 2;
+    if (fz.slot_scale != nullptr) slot_scale = fz.slot_scale[slot];
+  }
   const int xbytes = M * XS * 2;                         // staged x of one wave
   unsigned char* const stg = (unsigned char*)(red + (size_t)W * M * 16 * G) + (size_t)wave * (xbytes + G * T * 64 + 16);
 
@@ -546,6 +564,7 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
         uv += red[((size_t)w * M + m) * SW + cgate + 16];
       }
       if constexpr (NORM) { gv *= inv_rms[m]; uv *= inv_rms[m]; }
+      gv *= slot_scale; uv *= slot_scale;
       const float xg = (float)(half_t)gv;                                // the unfused path rounds gate_up to fp16 first
       ((half_t*)y)[(size_t)m * I + n] = (half_t)(xg / (1.f + __expf(-xg))) * (half_t)uv;
     }
@@ -558,6 +577,7 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
 #pragma unroll
       for (int w = 1; w < W; ++w) v += red[((size_t)w * M + m) * SW + col];
       if constexpr (NORM) v *= inv_rms[m];
+      v *= slot_scale;                                   // 1.0 outside the MoE route: exact
       store_output<AWQ_DTYPE_F16>(y, (size_t)m * N + n, v, bias, n);
     }
   }
@@ -583,14 +603,15 @@ static bool rp2_launch_t(const GemmArgs& a, const void* packed, int NG, int chun
     int lg = 0;
     while ((1 << lg) < gk) ++lg;
     const int gshift = 12 + lg, gmul = (int)(((1ll << gshift) + gk - 1) / gk);
-    const RpFuse fz = {(const half_t*)a.norm_h, (const half_t*)a.norm_delta, (const half_t*)a.norm_w, (half_t*)a.norm_h_out, a.norm_eps};
+    const RpFuse fz = {(const half_t*)a.norm_h, (const half_t*)a.norm_delta, (const half_t*)a.norm_w, (half_t*)a.norm_h_out, a.norm_eps,
+                      a.moe_expert_ids, a.moe_slot_scale, (long long)a.moe_expert_stride, a.moe_x_div};
 #define RP2_GO(CHS, DEP, ONE, NRM)                                                                                                 \
     do {                                                                                                                           \
       auto kern = gemv_rp2_kernel<G, T, CHS, DEP, EPI, ONE, NRM>;                                                                  \
       static unsigned long long opted[2] = {0ull, 0ull};                                                                           \
       if (lds > 64 * 1024 && !opt_in_dynamic_lds((const void*)kern, kRpMaxLds, opted)) return false;                                \
-      hipLaunchKernelGGL(kern, dim3(nwg), dim3(1024), lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r, a.bias, a.y, a.M, a.K, \
-                         a.N, a.K / a.g, gmul, gshift, NG, fz);                                                                    \
+      hipLaunchKernelGGL(kern, dim3(nwg, a.moe_slots > 0 ? a.moe_slots : 1), dim3(1024), lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r, \
+                         a.bias, a.y, a.M, a.K, a.N, a.K / a.g, gmul, gshift, NG, fz);                                              \
       return true;                                                                                                                 \
     } while (0)
     static const bool env_m1 = !(getenv("AWQ_RP2_M1") && atoi(getenv("AWQ_RP2_M1")) == 0);   // A/B knob
@@ -687,7 +708,8 @@ template <int G, int W, bool NT, int MT, int PRO, int EPI>
 static bool rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wave, int T, int nwg, size_t lds) {
   const u32x4_t* qw_r = (const u32x4_t*)packed;
   const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
-  const RpFuse fz = {(const half_t*)a.norm_h, (const half_t*)a.norm_delta, (const half_t*)a.norm_w, (half_t*)a.norm_h_out, a.norm_eps};
+  const RpFuse fz = {(const half_t*)a.norm_h, (const half_t*)a.norm_delta, (const half_t*)a.norm_w, (half_t*)a.norm_h_out, a.norm_eps,
+                      a.moe_expert_ids, a.moe_slot_scale, (long long)a.moe_expert_stride, a.moe_x_div};
   dim3 grid(nwg), block(W * 64);
 #define RP_GO(TT)                                                                                                                     \
   if constexpr ((PRO == 0 && EPI == 0) ? (TT <= 6 && rp_fits(W, MT, G, TT) && (MT == 1 || TT == 0 || TT == 4))                           \

@@ -316,3 +316,71 @@ def test_repacked_small_group_one_hot_rows_reproduce_dequantize(ops):
         idx = torch.arange(200, device=DEV) * 7 % K
         xb[torch.arange(200, device=DEV), idx] = 1.0
         assert torch.equal(ops.awq_gemm_repacked(xb, packed, K, N, g), W[idx]), dt + " tiled"
+
+
+@pytest.mark.parametrize("T", [1, 3, 8, 40])
+def test_awq_moe_method_vs_oracle(ops, T):
+    """AWQMoEMethod (reference awq.py:661-852): experts on the fragment-major layout, decode batches through the
+    expert-indirect GEMV (awq_aux_moe_gemv: SiLU-mul epilogue, routed weight on the fp32 sums), larger ones grouped by expert.
+    Oracle: the dense linear's exact sums per (token, expert), composed in numpy in the order of the reference's fused MoE
+    (fp16 gate_up -> fp16 silu * up -> fp16(weight * sum) -> fp16 sum over the token's experts).  Parity unpinned by the
+    reference beyond the dense path (no MoE fixtures)."""
+    from sglang_awq_amd.awq import AWQConfig
+    from sglang_awq_amd.moe import AWQMoEMethod, select_experts
+
+    E, K, I, top_k, g = 6, 2048, 1024, 2, 128
+    method = AWQMoEMethod(AWQConfig(4, g, True))
+    layer = torch.nn.Module()
+    method.create_weights(layer, E, K, I, torch.float16)
+    assert layer.w13_qweight.shape == (E, K, 2 * I // 8) and layer.w2_qweight.shape == (E, I, K // 8)
+    assert layer.w13_scales.shape == (E, K // g, 2 * I) and layer.w2_qzeros.shape == (E, I // g, K // 8)
+    w13 = [synth.make_awq_weights(K, 2 * I, g, "f16", "A", seed=100 + e) for e in range(E)]
+    w2 = [synth.make_awq_weights(I, K, g, "f16", "A", seed=200 + e) for e in range(E)]
+    for e in range(E):
+        layer.w13_qweight.data[e].copy_(to_torch(w13[e][0])); layer.w13_scales.data[e].copy_(to_torch(w13[e][1])); layer.w13_qzeros.data[e].copy_(to_torch(w13[e][2]))
+        layer.w2_qweight.data[e].copy_(to_torch(w2[e][0])); layer.w2_scales.data[e].copy_(to_torch(w2[e][1])); layer.w2_qzeros.data[e].copy_(to_torch(w2[e][2]))
+    layer.to(DEV)
+    method.process_weights_after_loading(layer)
+
+    x = synth.make_activations(T, K, "f16", "A", seed=T, x_std=0.5)
+    logits = synth.make_activations(T, E, "f16", "A", seed=T + 50).astype(np.float32)
+    tw, ti = select_experts(to_torch(logits, DEV), top_k)
+    assert ti.shape == (T, top_k) and torch.allclose(tw.sum(-1), torch.ones(T, device=DEV), atol=1e-6)
+    out = to_np(method.apply(layer, to_torch(x, DEV), tw, ti)).astype(np.float64)
+    tw_np, ti_np = tw.cpu().numpy().astype(np.float64), ti.cpu().numpy()
+
+    want = np.zeros((T, K))
+    scale = np.zeros((T, K))
+    for t in range(T):
+        for k in range(top_k):
+            e = int(ti_np[t, k])
+            _, gu = c_oracle.gemm(x[t:t + 1], *w13[e], want_exact=True)
+            gu = gu.astype(np.float16)
+            gate, up = gu[:, :I].astype(np.float32), gu[:, I:]
+            act = (gate / (1.0 + np.exp(-gate))).astype(np.float16) * up
+            _, y = c_oracle.gemm(act, *w2[e], want_exact=True)
+            ys = (tw_np[t, k] * y[0]).astype(np.float16).astype(np.float64)
+            want[t] += ys
+            scale[t] += np.abs(ys)
+    want = want.astype(np.float16).astype(np.float64)
+    # the kernel's silu (__expf) may land on a neighbouring half for some act elements, which moves a w2 sum by a few 1e-4
+    # relative; each slot and the final sum round once more
+    tol = 2.5 * (2.0 ** (np.floor(np.log2(np.maximum(scale, 2.0 ** -14))) - 10)) + 2e-3 * (1.0 + scale)
+    err = np.abs(out - want)
+    assert np.all(err <= tol), f"T={T}: worst {err.max():.3e} at scale {scale.flat[err.argmax()]:.3f}"
+    # the grouped route (T = 40) rounds a pair's sum before applying the routed weight: more one-ulp differences, same bound
+    assert float((out != want).mean()) < (0.25 if T * top_k <= AWQMoEMethod.MOE_GEMV_MAX_SLOTS else 0.45)
+    if T * top_k <= AWQMoEMethod.MOE_GEMV_MAX_SLOTS:
+        # the decode route holds no host synchronisation: it must capture into a graph and replay to the same bits
+        xt = to_torch(x, DEV)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            eager = method.apply(layer, xt, tw, ti)
+        torch.cuda.current_stream().wait_stream(side)
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph, stream=side):
+            captured = method.apply(layer, xt, tw, ti)
+        gph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(captured, eager)

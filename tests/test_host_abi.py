@@ -218,3 +218,24 @@ def test_python_shim_checks_the_repacked_buffer():
     ops.check_packed(torch.empty(688 * 32 * 1024 + 688 * 64 * 64, dtype=torch.uint8), 4096, 11008, 64, cpu, torch.bfloat16)
     with pytest.raises(ops.AwqHipError):
         ops.check_packed(torch.empty(16, dtype=torch.uint8), 4096, 11008, 16, cpu)        # no layout for g = 16
+
+
+def test_awq_moe_method_weight_shapes_cpu():
+    """AWQMoEMethod.create_weights registers the reference's six parameters with its shapes (awq.py:669-757) and rejects
+    misaligned expert sizes; no GPU needed."""
+    from sglang_awq_amd.awq import AWQConfig
+    from sglang_awq_amd.moe import AWQMoEMethod, select_experts
+
+    m = AWQMoEMethod(AWQConfig(4, 128, True))
+    layer = torch.nn.Module()
+    m.create_weights(layer, 8, 4096, 14336, torch.float16, weight_loader=None)
+    shapes = {n: tuple(p.shape) for n, p in layer.named_parameters()}
+    assert shapes == {"w13_qweight": (8, 4096, 3584), "w2_qweight": (8, 14336, 512), "w13_scales": (8, 32, 28672),
+                      "w2_scales": (8, 112, 4096), "w13_qzeros": (8, 32, 3584), "w2_qzeros": (8, 112, 512)}
+    assert layer.w13_qweight.dtype == torch.int32 and layer.w2_scales.dtype == torch.float16
+    with pytest.raises(ValueError):
+        m.create_weights(torch.nn.Module(), 2, 4096, 100, torch.float16)
+    with pytest.raises(ValueError):
+        AWQMoEMethod(AWQConfig.__new__(AWQConfig)) if False else AWQMoEMethod(type("C", (), {"weight_bits": 8, "group_size": 128, "pack_factor": 4})())
+    w, i = select_experts(torch.tensor([[0.0, 2.0, 1.0, -1.0]]), 2)
+    assert i.tolist() == [[1, 2]] and abs(float(w.sum()) - 1.0) < 1e-6 and w[0, 0] > w[0, 1]

@@ -1,0 +1,37 @@
+"""Timing of an AWQ-MoE decode step (Mixtral-8x7B-like expert shapes: E = 8, K = 4096, I = 14336, top-2) on the expert-indirect GEMV."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from sglang_awq_amd.awq import AWQConfig
+from sglang_awq_amd.moe import AWQMoEMethod, select_experts
+
+dev = torch.device("cuda:0")
+E, K, I, top_k, g = 8, 4096, 14336, 2, 128
+m = AWQMoEMethod(AWQConfig(4, g, True))
+layer = torch.nn.Module()
+m.create_weights(layer, E, K, I, torch.float16)
+layer.to(dev)
+gen = torch.Generator(device=dev); gen.manual_seed(0)
+for n, p in layer.named_parameters():
+    if p.dtype == torch.int32:
+        p.data.copy_(torch.randint(-2 ** 31, 2 ** 31 - 1, p.shape, dtype=torch.int64, device=dev, generator=gen).to(torch.int32))
+    else:
+        p.data.copy_((0.005 + 0.015 * torch.rand(p.shape, device=dev, generator=gen)).half())
+m.process_weights_after_loading(layer)
+wbytes = (layer.w13_packed.shape[1] + layer.w2_packed.shape[1])
+for T in (1, 2, 4, 8, 16):
+    x = torch.randn(T, K, device=dev, generator=gen).half() * 0.5
+    tw, ti = select_experts(torch.randn(T, E, device=dev, generator=gen), top_k)
+    m.apply(layer, x, tw, ti); torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        y = m.apply(layer, x, tw, ti)
+    gr.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        gr.replay()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 50
+    slots = T * top_k
+    print(f"T={T:2d} slots={slots:2d}: {us:8.1f} us per MoE layer  ({slots * wbytes / us / 1e3:7.1f} GB/s of expert weights streamed per slot)", flush=True)
