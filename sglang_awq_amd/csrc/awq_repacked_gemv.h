@@ -620,7 +620,8 @@ static bool rp2_launch_t(const GemmArgs& a, const void* packed, int NG, int chun
       if (chunks == 1) RP2_GO(1, 2, false, true);
       if (chunks == 2) RP2_GO(2, 2, false, true);
       if (chunks == 4) RP2_GO(4, 2, false, true);
-      if (chunks == 8) RP2_GO(8, 2, false, true);
+      // (8 chunks per lane would hold 3 x 8 staged vectors beside the weight ring: over the 128-register budget of a 16-wave
+      // workgroup — tools/rp_resources.py showed scratch; those batches run the norm as its own launch)
     } else {
       if (a.M == 1 && env_m1) {
         constexpr int C1 = (T * 16 + G * T * 4 + 63) / 64;          // <= 5 for G T <= 16

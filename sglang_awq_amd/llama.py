@@ -121,7 +121,8 @@ class LlamaDecoderLayer(torch.nn.Module):
         # the norm is folded through the GEMV (gemv_rp2_kernel<NORM>: x' = (h + delta) * w staged per wave, inv_rms applied to
         # the fp32 sums in the epilogue): 4096 x 12288 at 1 / 2 / 4 / 8 rows 7.4 / 8.3 / 8.7 / 10.1 us against 8.9 / 9.2 / 11.0 /
         # 14.5 for the earlier prologue form and ~4.7 us for a separate norm launch; the SiLU-mul epilogue is free at every batch
-        # size.  Beyond 16 rows the GEMV runs two row tiles per fragment and the norm is its own launch.
+        # size.  The folded form exists up to 4 staging chunks per lane (8 rows at K = 4096, 4 at K = 8192); beyond that the call
+    # returns None and the norm is its own launch (as it is past 16 rows, where the GEMV runs two row tiles per fragment).
         fuse_norm = B <= self.FUSE_NORM_MAX_BATCH
         qkv = None
         packed = getattr(self.qkv_proj, "awq_packed", None)

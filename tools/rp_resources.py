@@ -7,7 +7,8 @@ run it after touching the kernel.  Exit status 1 if any built instantiation uses
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRCS = [os.path.join(ROOT, "sglang_awq_amd", "csrc", f) for f in ("awq_repacked.hip", "awq_repacked_fused.hip")]
+SRCS = [os.path.join(ROOT, "sglang_awq_amd", "csrc", f) for f in ("awq_repacked.hip", "awq_repacked_fused.hip", "awq_repacked_ext.hip",
+                                                                   "awq_repacked_prefill.hip")]
 
 
 def main():
@@ -35,8 +36,24 @@ def main():
     for r in rows:
         print("PRO%-2d EPI%d MT%d W%-2d NT%d G%d T%d  vgpr %3d  scratch %4d  occupancy %d" % r)
         bad += r[8] > 0
-    print(f"{len(rows)} instantiations, {bad} with scratch")
-    return 1 if bad else 0
+    print(f"{len(rows)} gemv_repacked_kernel instantiations, {bad} with scratch")
+    # every other kernel of these files (gemv_rp2_kernel, gemv_rpx_kernel, the prefill kernels, repack): scratch must be 0 too
+    other, other_bad, worst = 0, [], {}
+    for blk in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
+        name = blk.split()[0]
+        if "gemv_repacked_kernelI" in name:
+            continue
+        mm = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", blk)
+        vg = re.search(r" VGPRs: (\d+)", blk)
+        other += 1
+        fam = re.sub(r"I.*", "", name.replace("_ZN3awq", ""))
+        worst[fam] = max(worst.get(fam, 0), int(vg.group(1)) if vg else 0)
+        if mm and int(mm.group(1)) > 0:
+            other_bad.append(name)
+    print(f"{other} other kernels, {len(other_bad)} with scratch; max VGPRs per family: " + ", ".join(f"{k} {v}" for k, v in sorted(worst.items())))
+    for n in other_bad[:20]:
+        print("  scratch:", n)
+    return 1 if (bad or other_bad) else 0
 
 
 if __name__ == "__main__":
