@@ -249,7 +249,7 @@ int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed) {
   const u32x4_t* qw_r = (const u32x4_t*)packed;
   const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
   // Tile quantisation: nA column tiles of 256 (16 groups) + the remaining groups in tiles of 192 (12 groups, 0.75 of the time).
-  // Cost in rounds of the 256 CUs: ceil(tiles_A / 256) + 0.75 ceil(tiles_B / 256) (+ a little for the second launch); the
+  // Cost in rounds of the 256 CUs: ceil(tiles_A / 256) + 0.84 ceil(tiles_B / 256) (+ a little for the second launch); the
   // smallest wins, ties go to fewer launches / wider tiles.  2048 x 11008: 32 x 16 = 512 wide tiles (2 rounds) + 15 x 16 = 240
   // narrow ones (0.75) instead of 688 wide ones (3 rounds).  AWQ_PF_SPLIT=0 keeps the single launch (A/B).
   static const bool env_split = !(getenv("AWQ_PF_SPLIT") && atoi(getenv("AWQ_PF_SPLIT")) == 0);
@@ -260,7 +260,8 @@ int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed) {
     const int rest = NG - 16 * nA > 0 ? NG - 16 * nA : 0;
     const int nB = (rest + 11) / 12;
     if (nA == 0 && nB == 0) continue;
-    const double cost = (double)((nA * nby + 255) / 256) + 0.75 * (double)((nB * nby + 255) / 256) + (nA > 0 && nB > 0 ? 0.02 : 0.0);
+    // a round of narrow tiles measured 0.84 of a round of wide ones (62 vs 73.5 us at K = 4096: the x-tile staging does not shrink)
+    const double cost = (double)((nA * nby + 255) / 256) + 0.84 * (double)((nB * nby + 255) / 256) + (nA > 0 && nB > 0 ? 0.02 : 0.0);
     if (cost < best - 1e-9) { best = cost; best_nA = nA; }
   }
   const int gA = best_nA * 16 < NG ? best_nA * 16 : NG;

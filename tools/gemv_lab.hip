@@ -528,6 +528,10 @@ static const Variant kVariants4096[] = {
     V3(3, 2, 16, 2, 0, 1, 4),
     V3(3, 2, 16, 2, 0, 1, 20),
     V3(3, 2, 16, 2, 0, 1, 52),
+    V3(3, 2, 16, 2, 0, 1, 53),
+    V3(3, 2, 16, 2, 2, 1, 52),
+    V3(3, 2, 16, 2, 4, 1, 52),
+    V3(3, 2, 16, 2, 5, 1, 52),
     V3(3, 2, 16, 2, 0, 1, 36),
     V3(3, 2, 16, 0, 0, 1, 16),
     V3(3, 2, 16, 0, 0, 1, 32),
