@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void repack_zs_kernel(const uint32_t* __restri
 // against 890-960 for the pipelined kernel at 2048 x 4096 x 11008) were removed after round 1; DESIGN.md §5.4 keeps the numbers.
 int launch_gemm_repacked_tiled(const GemmArgs& a, const void* packed) {
   if (!repacked_supported(a.K, a.N, a.g, a.dtype) || a.M < 1 || a.ldx % 8 || (((uintptr_t)a.x) & 15)) return AWQ_ERR_BAD_VARIANT;
-  if (!repacked_fast(a.K, a.N, a.g, a.dtype)) return launch_gemm_repacked_tiled_ext(a, packed);     // bf16 / g in {32, 64}
+  if (!repacked_fast(a.K, a.N, a.g, a.dtype) || !pipelined_addressable(a)) return launch_gemm_repacked_tiled_ext(a, packed);     // bf16 / g in {32, 64}
   return launch_gemm_repacked_pipelined(a, packed);
 }
 

@@ -17,7 +17,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "awq_repacked_gemv.h"
+#include "awq_prefill_common.h"
 
 namespace awq {
 
@@ -40,38 +40,17 @@ __device__ __forceinline__ void dq_stage(DqPipe& p, half2_t z1024, half2_t z64, 
   if constexpr (S == 6) { p.f[3] = as_u32(p.d3 * s2); }
 }
 
-__device__ __forceinline__ void mfma_tied(float4_t& acc, const u32x4_t& a, const u32x4_t& b) {
-  asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-}
-
-__device__ __forceinline__ int pfp_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }   // [rows][128 halves]
-
-// A value loaded at the top of a k-block but first needed late in it: without this, hipcc hoists the (pure) consumer
-// up to the load and waits out the whole load latency at the top of the block (`s_waitcnt vmcnt` right behind the
-// loads — a quarter of the kernel's wave-cycles).  The volatile pass-through cannot cross the sched_barriers.
-__device__ __forceinline__ void pin_here(uint32_t& v) { asm volatile("" : "+v"(v)); }
-
-struct ZsU { half2_t s2, z1024, z64; };
-__device__ __forceinline__ ZsU zs_unpack(uint32_t zs) {
-  const half2_t c960 = {(half_t)960.f, (half_t)960.f};
-  ZsU u;
-  u.s2 = as_h2(pack_lo16(zs, zs));
-  u.z1024 = as_h2(pack_hi16(zs, zs));
-  u.z64 = u.z1024 - c960;                               // exact: (1024 + z) - 960
-  return u;
-}
-
 #ifndef PF_ABL
 #define PF_ABL 0            // diagnostic builds only (timing ablations; results are wrong): 1 no dequant stages, 2 no LDS fragment reads in the loop, 4 no x-tile loads / LDS writes, 8 no barrier
 #endif
-constexpr int kPfBM = 128, kPfThreads = 256;
+constexpr int kPfThreads = 256;
 
 // NJ = column groups (16 columns) per wave: 4 -> 128 x 256 tiles, 3 -> 128 x 192 tiles (three quarters of the time per tile).
 // A launch covers the column groups [cg_base, cg_base + ng_region) of the matrix; the host cuts N into a region of 256-wide
 // tiles that fills whole rounds of the 256 CUs and a remainder of 192-wide tiles, so that 2048 x 11008 costs 2 + 0.75 rounds
 // instead of the 3 that 688 equal tiles pay for 2.69 (launch_gemm_repacked_pipelined).
-template <int NJ>
-__global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+template <int NJ, int OCC = 1>
+__global__ __launch_bounds__(kPfThreads, OCC) void gemm_repacked_pipelined_kernel(const uint16_t* __restrict__ x, int64_t ldx,
                                                                                 const u32x4_t* __restrict__ qw_r,
                                                                                 const uint32_t* __restrict__ zs_r,
                                                                                 const void* __restrict__ bias, void* __restrict__ y, int M,
@@ -79,9 +58,10 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
                                                                                 int ng_region) {
   extern __shared__ __attribute__((aligned(16))) unsigned char As[];      // 2 x 32 KiB
   constexpr int MI = 8, AL = 8;                     // row tiles per wave; x-tile chunks (16 B) per thread
-  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
-  const int q = lane >> 4, r = lane & 15;
-  const int KB = K / 128, groups = K / g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform on purpose: every weight / scale address below is
+  const int q = lane >> 4, r = lane & 15;                          // an SGPR base + a 32-bit lane offset (no 64-bit VALU address math
+  const int KB = K / 128, groups = K / g, kpg = g / 128;           // in the loop: it is not hidden behind the MFMAs)
 
   const int nwg = nbx * nby, bid = blockIdx.x;
   const int xcd = bid & 7, qd = nwg >> 3, rem = nwg & 7;
@@ -90,40 +70,49 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
   const int cg_tile = cg_base + (logical % nbx) * (4 * NJ) + wn * NJ;       // this wave's first column group
   const int cg_end = cg_base + ng_region < NG ? cg_base + ng_region : NG;
 
-  int cg[NJ];
+  // Every global load of the loop is a buffer load: SGPR descriptor + 32-bit lane offset + scalar offset (k-block, group), so the
+  // k-block's addresses cost a few SALU ops instead of ~60 64-bit VALU ops per k-block in front of the first MFMA.
+  constexpr int kRsrcFlags = kPfRsrcFlags;
+  __amdgpu_buffer_rsrc_t rw[NJ];                       // this wave's column groups: [KB][64 lanes] dwordx4
+  uint32_t zoff_s[NJ];                                 // byte offset of the group's first scale word in zs_r
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int c = cg_tile + j;
-    cg[j] = c < cg_end ? c : cg_end - 1;               // clamped: groups outside the region are never stored
+    const int cgj = c < cg_end ? c : cg_end - 1;       // clamped: groups outside the region are never stored
+    rw[j] = __builtin_amdgcn_make_buffer_rsrc((void*)(qw_r + (size_t)cgj * KB * 64), 0, KB * 1024, kRsrcFlags);
+    zoff_s[j] = (uint32_t)cgj * (uint32_t)groups * 64u;
   }
+  const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)zs_r, 0, 0x7fffffff, kRsrcFlags);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)bm * ldx), 0, 0x7fffffff, kRsrcFlags);
+  const int lane16 = lane * 16, r4 = r * 4;
 
   u32x4_t a_st[AL];
   u32x4_t w_cur[NJ], w_nxt[NJ];
   uint32_t zs_nxt[NJ];
   ZsU zu[NJ], zu_nxt[NJ];
 
-  const uint16_t* xrow[AL];                            // this thread's AL rows / chunks of the x tile, k-block 0
+  // this thread's AL rows / chunks of the x tile: byte offsets from the tile's first row
+  uint32_t xoff[AL];
 #pragma unroll
   for (int i = 0; i < AL; ++i) {
     const int c = tid + kPfThreads * i;
     const int row = c >> 4, chunk = c & 15;
-    const int m = bm + row < M ? bm + row : M - 1;
-    xrow[i] = x + (size_t)m * ldx + chunk * 8;
+    const int mr = bm + row < M ? row : M - 1 - bm;
+    xoff[i] = (uint32_t)((size_t)mr * ldx + chunk * 8) * 2u;
   }
   auto load_a = [&](int kb) {
 #pragma unroll
-    for (int i = 0; i < AL; ++i) a_st[i] = *(const u32x4_t*)(xrow[i] + kb * 128);
+    for (int i = 0; i < AL; ++i) a_st[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff[i], kb * 256, 0);
   };
   auto store_a1 = [&](int buf, int i) {
     const int c = tid + kPfThreads * i;
     *(u32x4_t*)(As + buf * (kPfBM * 256) + pfp_off(c >> 4, c & 15)) = a_st[i];
   };
-  auto load_b = [&](u32x4_t (&w)[NJ], uint32_t (&zs)[NJ], int kb) {
-    const int grp = (kb * 128) / g;
+  auto load_b = [&](u32x4_t (&w)[NJ], uint32_t (&zs)[NJ], int kb, int grp) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      w[j] = qw_r[((size_t)cg[j] * KB + kb) * 64 + lane];
-      zs[j] = zs_r[((size_t)cg[j] * groups + grp) * 16 + r];
+      w[j] = __builtin_amdgcn_raw_buffer_load_b128(rw[j], lane16, kb * 1024, 0);
+      zs[j] = __builtin_amdgcn_raw_buffer_load_b32(rz, r4, zoff_s[j] + grp * 64, 0);
     }
   };
 
@@ -135,7 +124,8 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
 
   // prologue: x tile 0 into LDS, k-block 0's weights / scales in registers, its first fragment dequantised
   load_a(0);
-  load_b(w_cur, zs_nxt, 0);
+  load_b(w_cur, zs_nxt, 0, 0);
+  int grp_n = 0, cnt_n = 0;                            // quantisation group of the next k-block, counted up (no division in the loop)
 #pragma unroll
   for (int i = 0; i < AL; ++i) store_a1(0, i);
 #pragma unroll
@@ -157,7 +147,8 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
     const int nbuf = (kb + 1) & 1;
     const unsigned char* An = As + nbuf * (kPfBM * 256);
     const int nx2 = kb + 2 < KB ? kb + 2 : KB - 1;
-    load_b(w_nxt, zs_nxt, nxt);
+    if (kb + 1 < KB && ++cnt_n == kpg) { cnt_n = 0; ++grp_n; }
+    load_b(w_nxt, zs_nxt, nxt, grp_n);
     __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
@@ -184,25 +175,30 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
             default: break;
           }
           // passengers of the free slots
-          if (!(PF_ABL & 2) && d < 3 && j == 1) af_n[mi] = *(const u32x4_t*)(Ab + pfp_off(mi * 16 + r, (d + 1) * 4 + q));   // next k-step's x fragments
+          // (read in the order 7 .. 0: the first consumer, row tile 0, then waits for the youngest read, and the compiler emits one
+          // s_waitcnt per k-step instead of eight; the same for the x-tile registers written to LDS youngest first)
+          if (!(PF_ABL & 2) && d < 3 && j == 1) af_n[MI - 1 - mi] = *(const u32x4_t*)(Ab + pfp_off((MI - 1 - mi) * 16 + r, (d + 1) * 4 + q));   // next k-step's x fragments
           // next x tile -> the other buffer, one 1 KiB write every fourth MFMA (eight in a row from all four waves
           // collide with the fragment reads), then the tile after it is requested at once: the 16 workgroups of a
           // row of tiles ask for the same fresh lines together, so they take about a k-block to arrive
           if constexpr (NJ == 4) {
             if (!(PF_ABL & 4) && ((d == 1 && j >= 2) || (d == 2 && j <= 1)) && (mi & 3) == 0)
-              store_a1(nbuf, ((d - 1) * 4 + j - 2) * 2 + (mi >> 2));
+              store_a1(nbuf, AL - 1 - (((d - 1) * 4 + j - 2) * 2 + (mi >> 2)));
             if (!(PF_ABL & 4) && d == 2 && j == 2 && mi == 0) load_a(nx2);
             if (d == 2 && j == 3 && mi == 7) { pin_here(zs_nxt[0]); zu_nxt[0] = zs_unpack(zs_nxt[0]); }
           } else {
             // three fragments per k-step: the eight writes ride in (d, j) = (1, 2), (2, 0), (2, 2) behind MFMAs 0, 3, 6 (the j = 1
             // slots carry the fragment reads), the next tile is requested behind the last of them
-            const int slot = (d == 1 && j == 2) ? 0 : (d == 2 && j == 0) ? 1 : (d == 2 && j == 2) ? 2 : -1;     // (compile-time after unrolling)
-            if (!(PF_ABL & 4) && slot >= 0 && mi % 3 == 0 && slot * 3 + mi / 3 < AL) store_a1(nbuf, slot * 3 + mi / 3);
-            if (!(PF_ABL & 4) && d == 2 && j == 2 && mi == 7) load_a(nx2);
+            // (two per k-step: four writes each in (1, 0) and (2, 0), behind every second MFMA)
+            const int slot = NJ == 3 ? ((d == 1 && j == 2) ? 0 : (d == 2 && j == 0) ? 1 : (d == 2 && j == 2) ? 2 : -1)
+                                     : ((d == 1 && j == 0) ? 0 : (d == 2 && j == 0) ? 1 : -1);     // (compile-time after unrolling)
+            constexpr int PER = NJ == 3 ? 3 : 2, CNT = NJ == 3 ? 3 : 4;
+            if (!(PF_ABL & 4) && slot >= 0 && mi % PER == 0 && slot * CNT + mi / PER < AL) store_a1(nbuf, AL - 1 - (slot * CNT + mi / PER));
+            if (!(PF_ABL & 4) && d == 2 && j == NJ - 1 && mi == 7) load_a(nx2);
             if (d == 2 && j == 1 && mi == 7) { pin_here(zs_nxt[0]); zu_nxt[0] = zs_unpack(zs_nxt[0]); }
           }
           if (!(PF_ABL & 8) && d == 3 && j == 0 && mi == 0) __syncthreads();
-          if (!(PF_ABL & 2) && d == 3 && j == 1) af_n[mi] = *(const u32x4_t*)(An + pfp_off(mi * 16 + r, q));    // next k-block's first fragments
+          if (!(PF_ABL & 2) && d == 3 && j == 1) af_n[MI - 1 - mi] = *(const u32x4_t*)(An + pfp_off((MI - 1 - mi) * 16 + r, q));    // next k-block's first fragments
           if (d == 3 && j < NJ - 1 && mi == 7) { pin_here(zs_nxt[j + 1]); zu_nxt[j + 1] = zs_unpack(zs_nxt[j + 1]); }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -233,18 +229,26 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
     }
 }
 
-template <int NJ>
-static int pf_launch_region(const GemmArgs& a, const u32x4_t* qw_r, const uint32_t* zs_r, int NG, int cg_base, int ng_region) {
+template <int NJ, int OCC = 1>
+static int pf_launch_region(const GemmArgs& a, const u32x4_t* qw_r, const uint32_t* zs_r, int NG, int cg_base, int ng_region, size_t lds_pad = 0) {
   const int nbx = (ng_region + 4 * NJ - 1) / (4 * NJ), nby = (a.M + kPfBM - 1) / kPfBM;
-  const size_t lds = 2 * kPfBM * 256;
+  const size_t lds = 2 * kPfBM * 256 + lds_pad;
   static unsigned long long opted[2] = {0ull, 0ull};
-  if (!opt_in_dynamic_lds((const void*)gemm_repacked_pipelined_kernel<NJ>, (int)lds, opted)) return AWQ_ERR_LAUNCH;
-  hipLaunchKernelGGL(gemm_repacked_pipelined_kernel<NJ>, dim3(nbx * nby), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r,
+  if (!opt_in_dynamic_lds((const void*)gemm_repacked_pipelined_kernel<NJ, OCC>, (int)lds, opted)) return AWQ_ERR_LAUNCH;
+  hipLaunchKernelGGL((gemm_repacked_pipelined_kernel<NJ, OCC>), dim3(nbx * nby), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r,
                      zs_r, a.bias, a.y, a.M, a.K, a.N, a.g, NG, nbx, nby, cg_base, ng_region);
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
+// 32-bit offsets inside the kernel's buffer descriptors: a 128-row x tile, the scale words and one column group's strip of weights
+// must each span less than 2 GiB (any real layer does; callers fall back to the generic tiles otherwise).
+bool pipelined_addressable(const GemmArgs& a) {
+  const int64_t NG = rp_groups(a.N);
+  return a.ldx < (int64_t(1) << 22) && NG * (a.K / a.g) * 64 < (int64_t(1) << 31) && (int64_t)(a.K / 128) * 1024 < (int64_t(1) << 31);
+}
+
 int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed) {
+  if (!pipelined_addressable(a)) return AWQ_ERR_BAD_VARIANT;
   const int NG = rp_groups(a.N);
   const u32x4_t* qw_r = (const u32x4_t*)packed;
   const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
@@ -265,6 +269,8 @@ int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed) {
     if (cost < best - 1e-9) { best = cost; best_nA = nA; }
   }
   const int gA = best_nA * 16 < NG ? best_nA * 16 : NG;
+  static const int env_pc = getenv("AWQ_PF_PC") ? atoi(getenv("AWQ_PF_PC")) : 0;      // producer / consumer form (awq_repacked_prefill_pc.hip)
+  if (env_pc) return launch_gemm_repacked_pc(a, packed, gA);
   if (gA > 0) {
     const int rc = pf_launch_region<4>(a, qw_r, zs_r, NG, 0, gA);
     if (rc) return rc;

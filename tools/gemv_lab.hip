@@ -822,8 +822,171 @@ static int cmd_ubench(int, char**) {
   return 0;
 }
 
+// ---- overlap microbenchmark: can VALU work hide behind MFMAs (a) in the same wave, (b) from another wave of the same SIMD? ----
+// ROLE 0: 16 independent MFMA 16x16x32 per iteration.  ROLE 1: NV independent v_pk_mul_f16 per iteration.
+// ROLE 2: the same wave alternates 1 MFMA + 2 v_pk_mul (16 + 32 per iteration).  ROLE 3: even waves MFMA, waves 4..7 VALU (W = 8).
+template <int ROLE>
+__global__ __launch_bounds__(512) void overlap_kernel(uint32_t* out, unsigned long long* cyc, int iters, uint32_t seed) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool do_mfma = ROLE == 0 || ROLE == 2 || (ROLE == 3 && wave < 4);
+  const bool do_valu = ROLE == 1 || ROLE == 2 || (ROLE == 3 && wave >= 4);
+  float4_t acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  u32x4_t a = {0x3c003c00u + lane, 0x3c003c00u, 0x38003c00u, 0x3c003800u}, b = {seed + lane, seed ^ lane, seed, seed * 3u};
+  half2_t v[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) v[i] = as_h2(0x3c003c00u + i + lane);
+  const half2_t m = as_h2(0x3c013c01u);
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_readcyclecounter();
+  if (ROLE == 2) {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a), "v"(b));
+        asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(v[2 * i]) : "v"(m));
+        asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(v[2 * i + 1]) : "v"(m));
+      }
+    }
+  } else if (do_mfma) {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a), "v"(b));
+    }
+  } else if (do_valu) {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(v[i]) : "v"(m));
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_readcyclecounter();
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  if (lane == 0) { cyc[(blockIdx.x * 8 + wave) * 2] = t1 - t0; cyc[(blockIdx.x * 8 + wave) * 2 + 1] = r1 - r0; }
+  uint32_t x = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x ^= __builtin_bit_cast(uint32_t, acc[i][0]);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) x ^= as_u32(v[i]);
+  out[blockIdx.x * blockDim.x + threadIdx.x] = x;
+}
+
+static int cmd_overlap(int, char**) {
+  const int iters = 4000, nwg = 256;
+  uint32_t* out; unsigned long long* cyc;
+  CK(hipMalloc(&out, (size_t)nwg * 512 * 4)); CK(hipMalloc(&cyc, (size_t)nwg * 8 * 2 * 8));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  struct Cfg { int role, W; const char* name; };
+  const Cfg cfgs[] = {{0, 4, "16 MFMA / iter, 1 wave per SIMD"}, {1, 4, "32 v_pk_mul / iter, 1 wave per SIMD"}, {2, 4, "same wave: 16 x (MFMA + 2 v_pk_mul)"},
+                      {0, 8, "16 MFMA / iter, 2 waves per SIMD"}, {1, 8, "32 v_pk_mul / iter, 2 waves per SIMD"}, {2, 8, "same wave mix, 2 waves per SIMD"},
+                      {3, 8, "waves 0-3 MFMA, waves 4-7 VALU"}};
+  for (const Cfg& c : cfgs) {
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipMemset(cyc, 0, (size_t)nwg * 8 * 2 * 8));
+      CK(hipEventRecord(e0, 0));
+      switch (c.role) {
+        case 0: hipLaunchKernelGGL(overlap_kernel<0>, dim3(nwg), dim3(c.W * 64), 0, 0, out, cyc, iters, 12345u); break;
+        case 1: hipLaunchKernelGGL(overlap_kernel<1>, dim3(nwg), dim3(c.W * 64), 0, 0, out, cyc, iters, 12345u); break;
+        case 2: hipLaunchKernelGGL(overlap_kernel<2>, dim3(nwg), dim3(c.W * 64), 0, 0, out, cyc, iters, 12345u); break;
+        default: hipLaunchKernelGGL(overlap_kernel<3>, dim3(nwg), dim3(c.W * 64), 0, 0, out, cyc, iters, 12345u); break;
+      }
+      CK(hipEventRecord(e1, 0));
+      CK(hipDeviceSynchronize());
+      CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    std::vector<unsigned long long> h((size_t)nwg * 8 * 2);
+    CK(hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> lo, hi;                       // waves 0..3 / 4..7 of each workgroup: s_memtime ticks per iteration
+    for (int g = 0; g < nwg; ++g)
+      for (int w = 0; w < c.W; ++w) (w < 4 ? lo : hi).push_back((double)h[(g * 8 + w) * 2] / iters);
+    std::sort(lo.begin(), lo.end()); std::sort(hi.begin(), hi.end());
+    const double tick_ns = ms * 1e6 / ((double)h[0] > 0 ? (double)h[0] : 1.0);   // kernel time / ticks of one wave: upper bound of ns per tick
+    printf("overlap %-40s kernel %8.1f us  waves 0-3: %7.1f ticks/iter", c.name, ms * 1e3, lo[lo.size() / 2]);
+    if (!hi.empty()) printf("  waves 4-7: %7.1f ticks/iter", hi[hi.size() / 2]);
+    printf("  (ns per iteration %.1f; %.3f ns per tick)\n", ms * 1e6 / iters, tick_ns);
+  }
+  return 0;
+}
+
+// ---- VALU op rates: 32 independent ops per iteration, one wave per SIMD ----
+#define VOP_CASE(N, STR) if constexpr (OP == N) asm volatile(STR : "+v"(v[i]) : "v"(m), "v"(m2));
+template <int OP>
+__global__ __launch_bounds__(256) void valu_rate_kernel(uint32_t* out, unsigned long long* cyc, int iters) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t v[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) v[i] = 0x3c003c00u + i + lane;
+  const uint32_t m = 0x3c013c01u, m2 = 0x000f000fu;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      VOP_CASE(0, "v_pk_mul_f16 %0, %0, %1")
+      VOP_CASE(1, "v_pk_add_f16 %0, %0, %1")
+      VOP_CASE(2, "v_pk_fma_f16 %0, %0, %1, %2")
+      VOP_CASE(3, "v_and_or_b32 %0, %0, %2, %1")
+      VOP_CASE(4, "v_lshrrev_b32 %0, 8, %0")
+      VOP_CASE(5, "v_mul_f32 %0, %0, %1")
+      VOP_CASE(6, "v_fma_f32 %0, %0, %1, %2")
+      VOP_CASE(7, "v_xor_b32 %0, %0, %1")
+      VOP_CASE(8, "v_perm_b32 %0, %0, %1, %2")
+      VOP_CASE(9, "v_mul_f16 %0, %0, %1")
+      VOP_CASE(10, "v_add_u32 %0, %0, %1")
+      VOP_CASE(11, "v_pk_mul_f16 %0, %0, %1 op_sel_hi:[1,0]")
+      VOP_CASE(12, "v_and_b32 %0, %0, %2")
+      VOP_CASE(13, "v_mov_b32 %0, %1")
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) cyc[blockIdx.x * 4 + wave] = t1 - t0;
+  uint32_t x = 0;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) x ^= v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = x;
+}
+
+template <int OP>
+static void valu_rate_one(const char* name, uint32_t* out, unsigned long long* cyc) {
+  const int iters = 4000, nwg = 256;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float ms = 0;
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(valu_rate_kernel<OP>, dim3(nwg), dim3(256), 0, 0, out, cyc, iters);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    CK(hipEventElapsedTime(&ms, e0, e1));
+  }
+  std::vector<unsigned long long> h((size_t)nwg * 4);
+  CK(hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost));
+  std::sort(h.begin(), h.end());
+  printf("valu rate %-40s %6.2f s_memtime ticks per op   %6.3f ns per op (kernel time / ops)\n", name, (double)h[h.size() / 2] / (iters * 32.0), ms * 1e6 / (iters * 32.0));
+}
+
+static int cmd_valu_rate(int, char**) {
+  uint32_t* out; unsigned long long* cyc;
+  CK(hipMalloc(&out, (size_t)256 * 256 * 4)); CK(hipMalloc(&cyc, (size_t)256 * 4 * 8));
+  valu_rate_one<0>("v_pk_mul_f16", out, cyc);
+  valu_rate_one<1>("v_pk_add_f16", out, cyc);
+  valu_rate_one<2>("v_pk_fma_f16", out, cyc);
+  valu_rate_one<3>("v_and_or_b32", out, cyc);
+  valu_rate_one<4>("v_lshrrev_b32", out, cyc);
+  valu_rate_one<5>("v_mul_f32", out, cyc);
+  valu_rate_one<6>("v_fma_f32", out, cyc);
+  valu_rate_one<7>("v_xor_b32", out, cyc);
+  valu_rate_one<8>("v_perm_b32", out, cyc);
+  valu_rate_one<9>("v_mul_f16", out, cyc);
+  valu_rate_one<10>("v_add_u32", out, cyc);
+  valu_rate_one<11>("v_pk_mul_f16 op_sel_hi:[1,0]", out, cyc);
+  valu_rate_one<12>("v_and_b32", out, cyc);
+  valu_rate_one<13>("v_mov_b32", out, cyc);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc >= 2 && std::string(argv[1]) == "ubench") return cmd_ubench(argc, argv);
+  if (argc >= 2 && std::string(argv[1]) == "overlap") return cmd_overlap(argc, argv);
+  if (argc >= 2 && std::string(argv[1]) == "valu_rate") return cmd_valu_rate(argc, argv);
   if (argc < 4) { fprintf(stderr, "usage: gemv_lab time K N [sets] [iters] [filter] | stamps K N variant [sets]\n"); return 2; }
   std::string cmd = argv[1];
   if (cmd == "time") return cmd_time(argc, argv);
