@@ -49,8 +49,8 @@ constexpr int kPfThreads = 256;
 // A launch covers the column groups [cg_base, cg_base + ng_region) of the matrix; the host cuts N into a region of 256-wide
 // tiles that fills whole rounds of the 256 CUs and a remainder of 192-wide tiles, so that 2048 x 11008 costs 2 + 0.75 rounds
 // instead of the 3 that 688 equal tiles pay for 2.69 (launch_gemm_repacked_pipelined).
-template <int NJ, int OCC = 1>
-__global__ __launch_bounds__(kPfThreads, OCC) void gemm_repacked_pipelined_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+template <int NJ>
+__global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(const uint16_t* __restrict__ x, int64_t ldx,
                                                                                 const u32x4_t* __restrict__ qw_r,
                                                                                 const uint32_t* __restrict__ zs_r,
                                                                                 const void* __restrict__ bias, void* __restrict__ y, int M,
@@ -229,13 +229,13 @@ __global__ __launch_bounds__(kPfThreads, OCC) void gemm_repacked_pipelined_kerne
     }
 }
 
-template <int NJ, int OCC = 1>
-static int pf_launch_region(const GemmArgs& a, const u32x4_t* qw_r, const uint32_t* zs_r, int NG, int cg_base, int ng_region, size_t lds_pad = 0) {
+template <int NJ>
+static int pf_launch_region(const GemmArgs& a, const u32x4_t* qw_r, const uint32_t* zs_r, int NG, int cg_base, int ng_region) {
   const int nbx = (ng_region + 4 * NJ - 1) / (4 * NJ), nby = (a.M + kPfBM - 1) / kPfBM;
-  const size_t lds = 2 * kPfBM * 256 + lds_pad;
+  const size_t lds = 2 * kPfBM * 256;
   static unsigned long long opted[2] = {0ull, 0ull};
-  if (!opt_in_dynamic_lds((const void*)gemm_repacked_pipelined_kernel<NJ, OCC>, (int)lds, opted)) return AWQ_ERR_LAUNCH;
-  hipLaunchKernelGGL((gemm_repacked_pipelined_kernel<NJ, OCC>), dim3(nbx * nby), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r,
+  if (!opt_in_dynamic_lds((const void*)gemm_repacked_pipelined_kernel<NJ>, (int)lds, opted)) return AWQ_ERR_LAUNCH;
+  hipLaunchKernelGGL(gemm_repacked_pipelined_kernel<NJ>, dim3(nbx * nby), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r,
                      zs_r, a.bias, a.y, a.M, a.K, a.N, a.g, NG, nbx, nby, cg_base, ng_region);
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
@@ -269,8 +269,6 @@ int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed) {
     if (cost < best - 1e-9) { best = cost; best_nA = nA; }
   }
   const int gA = best_nA * 16 < NG ? best_nA * 16 : NG;
-  static const int env_pc = getenv("AWQ_PF_PC") ? atoi(getenv("AWQ_PF_PC")) : 0;      // producer / consumer form (awq_repacked_prefill_pc.hip)
-  if (env_pc) return launch_gemm_repacked_pc(a, packed, gA);
   if (gA > 0) {
     const int rc = pf_launch_region<4>(a, qw_r, zs_r, NG, 0, gA);
     if (rc) return rc;
