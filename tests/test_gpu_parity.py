@@ -275,13 +275,28 @@ def test_gemm_repacked_tiled_vs_oracle(ops):
     for (M, K, N, g) in [(33, 128, 128, 128), (64, 256, 136, 128), (150, 128, 16648, 128),            # GEMV passes
                          (100, 512, 1056, 128), (256, 1024, 256, 1024), (257, 384, 264, 128), (300, 256, 2304, 128),
                          (1024, 128, 64, 128), (97, 640, 72, 128),                                      # K-split tiles
-                         (600, 256, 4360, 128), (161, 384, 16640, 128), (520, 128, 3336, 128)]:         # pipelined tiles
+                         (600, 256, 4360, 128), (161, 384, 16640, 128), (520, 128, 3336, 128),          # pipelined tiles
+                         (300, 512, 5640, 256), (200, 384, 16648, 384), (385, 768, 5896, 384)]:         # ... groups of 2 / 3 k-blocks (counted, not divided)
         qw, s, qz = synth.make_awq_weights(K, N, g, "f16", "A", seed=M * 3 + K + N)
         x = synth.make_activations(M, K, "f16", "A", seed=M + K + 1)
         packed = ops.awq_repack(*_dev(qw, s, qz))
         y = to_np(ops.awq_gemm_repacked(to_torch(x, DEV), packed, K, N, g))
         _, exact = c_oracle.gemm(x, qw, s, qz, want_exact=True)
         assert_gemm_close(y, exact, "f16", what=f"repacked tiled M={M} K={K} N={N} g={g}")
+
+
+def test_gemm_repacked_tiled_strided_rows(ops):
+    """x as a column slice of a wider tensor (ldx > K) through the three M > 32 routes: the pipelined kernel addresses its x tile
+    through a buffer descriptor with 32-bit offsets from the tile's first row."""
+    for (M, K, N, g) in [(300, 256, 5640, 128), (257, 384, 264, 128), (150, 128, 2056, 128)]:
+        qw, s, qz = synth.make_awq_weights(K, N, g, "f16", "A", seed=M + K + N)
+        x = synth.make_activations(M, K + 72, "f16", "A", seed=M + 5)
+        packed = ops.awq_repack(*_dev(qw, s, qz))
+        xt = to_torch(x, DEV)[:, 40:40 + K]
+        assert xt.stride(0) == K + 72 and not xt.is_contiguous()
+        y = to_np(ops.awq_gemm_repacked(xt, packed, K, N, g))
+        _, exact = c_oracle.gemm(np.ascontiguousarray(x[:, 40:40 + K]), qw, s, qz, want_exact=True)
+        assert_gemm_close(y, exact, "f16", what=f"repacked tiled, strided x, M={M} K={K} N={N}")
 
 
 def test_gemm_repacked_tiled_prefill_shape_one_hot(ops):
