@@ -45,7 +45,7 @@ __device__ __forceinline__ void dq_stage(DqPipe& p, half2_t z1024, half2_t z64, 
 #endif
 constexpr int kPfThreads = 256;
 
-// NJ = column groups (16 columns) per wave: 4 -> 128 x 256 tiles, 3 -> 128 x 192 tiles (three quarters of the time per tile).
+// NJ = column groups (16 columns) per wave: 4 -> 128 x 256 tiles, 3 -> 128 x 192 tiles, 2 -> 128 x 128 tiles.
 // A launch covers the column groups [cg_base, cg_base + ng_region) of the matrix; the host cuts N into a region of 256-wide
 // tiles that fills whole rounds of the 256 CUs and a remainder of 192-wide tiles, so that 2048 x 11008 costs 2 + 0.75 rounds
 // instead of the 3 that 688 equal tiles pay for 2.69 (launch_gemm_repacked_pipelined).
@@ -269,6 +269,12 @@ int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed) {
     if (cost < best - 1e-9) { best = cost; best_nA = nA; }
   }
   const int gA = best_nA * 16 < NG ? best_nA * 16 : NG;
+  // Few row tiles (M up to ~384 on a wide matrix): 128 x 128 tiles (NJ = 2) fill more CUs per round; a round of them measured
+  // kNarrow2 of a round of wide ones.  Taken only when it beats the wide / 192-wide split.
+  constexpr double kNarrow2 = 0.65;      // 43.5 us for 172 tiles against 73.5 for a round of wide ones (M = 256, 4096 x 11008)
+  static const int env_nj2 = getenv("AWQ_PF_NJ2") ? atoi(getenv("AWQ_PF_NJ2")) : -1;      // A/B: 0 never, 1 always
+  const double cost2 = kNarrow2 * (double)((((NG + 7) / 8) * nby + 255) / 256);
+  if (env_nj2 == 1 || (env_nj2 != 0 && env_split && cost2 < best - 1e-9)) return pf_launch_region<2>(a, qw_r, zs_r, NG, 0, NG);
   if (gA > 0) {
     const int rc = pf_launch_region<4>(a, qw_r, zs_r, NG, 0, gA);
     if (rc) return rc;

@@ -276,7 +276,8 @@ def test_gemm_repacked_tiled_vs_oracle(ops):
                          (100, 512, 1056, 128), (256, 1024, 256, 1024), (257, 384, 264, 128), (300, 256, 2304, 128),
                          (1024, 128, 64, 128), (97, 640, 72, 128),                                      # K-split tiles
                          (600, 256, 4360, 128), (161, 384, 16640, 128), (520, 128, 3336, 128),          # pipelined tiles
-                         (300, 512, 5640, 256), (200, 384, 16648, 384), (385, 768, 5896, 384)]:         # ... groups of 2 / 3 k-blocks (counted, not divided)
+                         (300, 512, 5640, 256), (200, 384, 16648, 384), (385, 768, 5896, 384),          # ... groups of 2 / 3 k-blocks (counted, not divided)
+                         (200, 256, 8456, 128), (255, 128, 9000, 128)]:                                 # ... 128 x 128 tiles (two row tiles, wide matrix)
         qw, s, qz = synth.make_awq_weights(K, N, g, "f16", "A", seed=M * 3 + K + N)
         x = synth.make_activations(M, K, "f16", "A", seed=M + K + 1)
         packed = ops.awq_repack(*_dev(qw, s, qz))
