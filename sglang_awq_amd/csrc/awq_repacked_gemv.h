@@ -328,6 +328,9 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
 // order in the oracle and bound the distance to the eager order); workgroup 0 stores v = h + delta (fp16 add, bit-exact).
 // The earlier norm prologue (gemv_repacked_kernel, PRO > 0) needed every workgroup to re-read all of h + delta and one
 // workgroup barrier before its weight loads: +1.6 us at M = 1, +6.5 at M = 8; this form costs two extra staging loads.
+#ifndef RP2_EARLY
+#define RP2_EARLY 1           // 0: A/B build, the replacement load is issued behind the unit's compute (round-2 first form)
+#endif
 template <int G, int T, int CHS, int D, int EPI, bool M1, bool NORM = false>
 __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restrict__ x, int64_t ldx, const u32x4_t* __restrict__ qw_r,
                                                         const uint32_t* __restrict__ zs_r, const void* __restrict__ bias,
@@ -429,13 +432,17 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
   }
   // weights: wave-uniform base + lane offset; k-blocks past K are clamped (re-read, weighted by x = 0)
   const uint32_t loff = (uint32_t)lane * 16u;
-  u32x4_t wbuf[DD];
+  // DD loads in flight per wave, DD + 1 register sets: the load that replaces unit i is issued the moment unit i has arrived,
+  // BEFORE its 4 x (13 VALU + MFMA) are computed (behind them it would wait ~300 cycles of this wave's issue time, up to four
+  // times that with the SIMD's other waves in the way, and the wave would sit at one load in flight meanwhile)
+  constexpr int RB = (RP2_EARLY && M1 && DD < L) ? DD + 1 : DD;      // (one-row form only: at M = 4 / 16 it measured 1 % slower, at M = 1 0-3 % faster)
+  u32x4_t wbuf[RB];
   auto load_w = [&](int i) {
     const int t = i / G, c = i - t * G;
     int kb = kb0 + t;
     kb = kb < KB ? kb : KB - 1;
     const unsigned char* p = (const unsigned char*)(qw_r + ((size_t)(cg0 + c) * KB + kb) * 64) + loff;
-    wbuf[i % DD] = __builtin_nontemporal_load((const u32x4_t*)p);      // streamed once: keep it out of the caches' way
+    wbuf[i % RB] = __builtin_nontemporal_load((const u32x4_t*)p);      // streamed once: keep it out of the caches' way
   };
 #pragma unroll
   for (int i = 0; i < DD; ++i) {
@@ -501,7 +508,13 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
     const half2_t s2 = __builtin_shufflevector(zh, zh, 0, 0);          // folded into op_sel of the packed ops
     const half2_t z1024 = __builtin_shufflevector(zh, zh, 1, 1);
     const half2_t z64 = z1024 - c960;                                    // exact: (1024 + z) - 960
-    const u32x4_t w = wbuf[i % DD];
+    u32x4_t w = wbuf[i % RB];
+    if (RB > DD && i + DD < L) {
+      asm volatile("" : "+v"(w));                        // unit i has arrived (the wait sits here) ...
+      __builtin_amdgcn_sched_barrier(0);
+      load_w(i + DD);                                    // ... its replacement leaves at once, into the spare register set
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       const uint32_t ww = w[d], w8 = ww >> 8;
@@ -513,7 +526,7 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
       acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, xa[d]), __builtin_bit_cast(half8_t, frag), acc[c], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (i + DD < L) {
+    if (RB == DD && i + DD < L) {
       load_w(i + DD);
       __builtin_amdgcn_sched_barrier(0);
     }
