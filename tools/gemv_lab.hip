@@ -983,10 +983,71 @@ static int cmd_valu_rate(int, char**) {
   return 0;
 }
 
+// ---- how many independent VALU ops hide behind one MFMA of the SAME wave?  16x16x32 (16 cycles) vs 32x32x16 (32 cycles) ----
+typedef float float16_t __attribute__((ext_vector_type(16)));
+template <int BIG, int NV>
+__global__ __launch_bounds__(256) void hide_kernel(uint32_t* out, unsigned long long* cyc, int iters, uint32_t seed) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4_t acc4[8];
+  float16_t acc16[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    acc4[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc16[i][e] = 0.f;
+  }
+  u32x4_t a = {0x3c003c00u + lane, 0x3c003c00u, 0x38003c00u, 0x3c003800u}, b = {seed + lane, seed ^ lane, seed, seed * 3u};
+  uint32_t v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = 0x3c003c00u + i + lane;
+  const uint32_t m = 0x3c013c01u;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if constexpr (BIG) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc16[i]) : "v"(a), "v"(b));
+      else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc4[i]) : "v"(a), "v"(b));
+#pragma unroll
+      for (int k = 0; k < NV; ++k) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(v[k % 8]) : "v"(m));
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  if (lane == 0) cyc[blockIdx.x * 4 + wave] = t1 - t0;
+  uint32_t x = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { x ^= __builtin_bit_cast(uint32_t, acc4[i][0]) ^ __builtin_bit_cast(uint32_t, acc16[i][0]) ^ v[i]; }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = x;
+}
+
+template <int BIG, int NV>
+static void hide_one(uint32_t* out, unsigned long long* cyc) {
+  const int iters = 4000, nwg = 256;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipLaunchKernelGGL((hide_kernel<BIG, NV>), dim3(nwg), dim3(256), 0, 0, out, cyc, iters, 12345u);
+    CK(hipDeviceSynchronize());
+  }
+  std::vector<unsigned long long> h((size_t)nwg * 4);
+  CK(hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost));
+  std::sort(h.begin(), h.end());
+  printf("hide  %-22s + %d v_pk_mul_f16 : %6.1f s_memtime ticks per MFMA\n", BIG ? "v_mfma_f32_32x32x16_f16" : "v_mfma_f32_16x16x32_f16", NV,
+         (double)h[h.size() / 2] / (iters * 8.0));
+}
+
+static int cmd_hide(int, char**) {
+  uint32_t* out; unsigned long long* cyc;
+  CK(hipMalloc(&out, (size_t)256 * 256 * 4)); CK(hipMalloc(&cyc, (size_t)256 * 4 * 8));
+  hide_one<0, 0>(out, cyc); hide_one<0, 1>(out, cyc); hide_one<0, 2>(out, cyc); hide_one<0, 3>(out, cyc); hide_one<0, 4>(out, cyc);
+  hide_one<1, 0>(out, cyc); hide_one<1, 2>(out, cyc); hide_one<1, 4>(out, cyc); hide_one<1, 5>(out, cyc); hide_one<1, 6>(out, cyc);
+  hide_one<1, 8>(out, cyc);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc >= 2 && std::string(argv[1]) == "ubench") return cmd_ubench(argc, argv);
   if (argc >= 2 && std::string(argv[1]) == "overlap") return cmd_overlap(argc, argv);
   if (argc >= 2 && std::string(argv[1]) == "valu_rate") return cmd_valu_rate(argc, argv);
+  if (argc >= 2 && std::string(argv[1]) == "hide") return cmd_hide(argc, argv);
   if (argc < 4) { fprintf(stderr, "usage: gemv_lab time K N [sets] [iters] [filter] | stamps K N variant [sets]\n"); return 2; }
   std::string cmd = argv[1];
   if (cmd == "time") return cmd_time(argc, argv);
