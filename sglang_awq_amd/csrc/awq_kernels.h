@@ -60,7 +60,6 @@ bool repacked_supported(int64_t K, int64_t N, int64_t g, int dtype);
 // the subset with the tuned kernels (fp16, g % 128 == 0): straight-line GEMV, hand-pipelined prefill, fused decode variants
 bool repacked_fast(int64_t K, int64_t N, int64_t g, int dtype);
 bool pipelined_addressable(const GemmArgs& a);                                 // spans fit the prefill kernel's 32-bit buffer offsets
-int launch_gemm_repacked_pipelined32(const GemmArgs& a, const void* packed, int gA);   // 32x32x16 MFMA form (awq_repacked_prefill32.hip); groups [0, gA) in 128 x 256 tiles, the rest 128 x 128
 int launch_gemv_repacked_ext(const GemmArgs& a, const void* packed);          // bf16 / small groups, M <= 16 (awq_repacked_ext.hip)
 int launch_gemm_repacked_tiled_ext(const GemmArgs& a, const void* packed);    // bf16 / small groups, large M
 int launch_repack(const int32_t* qweight, const void* scales, const int32_t* qzeros, void* packed, int64_t K, int64_t N, int64_t g,

@@ -269,9 +269,6 @@ int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed) {
     if (cost < best - 1e-9) { best = cost; best_nA = nA; }
   }
   const int gA = best_nA * 16 < NG ? best_nA * 16 : NG;
-  static const int env_pf32 = getenv("AWQ_PF32") ? atoi(getenv("AWQ_PF32")) : 0;      // 1: 32x32x16 kernel, wide tiles only; 2: wide + 128-wide remainder
-  if (env_pf32 == 1) return launch_gemm_repacked_pipelined32(a, packed, NG);
-  if (env_pf32 == 2) return launch_gemm_repacked_pipelined32(a, packed, gA);
   // Few row tiles (M up to ~384 on a wide matrix): 128 x 128 tiles (NJ = 2) fill more CUs per round; a round of them measured
   // kNarrow2 of a round of wide ones.  Taken only when it beats the wide / 192-wide split.
   constexpr double kNarrow2 = 0.65;      // 43.5 us for 172 tiles against 73.5 for a round of wide ones (M = 256, 4096 x 11008)
