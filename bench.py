@@ -328,6 +328,15 @@ def main():
             use_graph = False
             graphs.clear()
             sync()
+    if world > 1 and not args.no_graph and not test_backend and not cpu_rehearsal:
+        # every rank replays or every rank launches eagerly: a rank whose capture failed must not leave the others replaying
+        ok = torch.tensor([1 if use_graph else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and use_graph:
+            use_graph = False
+            graphs.clear()
+            capture_error = capture_error or "capture failed on another rank"
+        sync()
 
 
     def timed_wall(n):
