@@ -128,6 +128,20 @@ int awq_repack(const int32_t* qweight, const void* scales, const int32_t* qzeros
 int awq_gemm_repacked(const void* x, int64_t ldx, const void* packed, const void* bias, void* y, int64_t M,
                       int64_t K, int64_t N, int64_t group_size, int dtype, void* stream);
 
+/*
+ * awq_gemm_repacked with an optional scratch buffer.  With 9 .. 32 rows on a narrow matrix (N <= 8192) the one-strip-per-workgroup
+ * GEMV re-reads all of x in every workgroup; given `workspace` (>= awq_gemm_repacked_workspace_bytes(), 16-byte aligned, its first
+ * 4096 bytes zero-filled ONCE when allocated — arrival counters, left at zero by every call — one buffer per stream of execution,
+ * the same rules as awq_gemm's) that case runs wide strips with K split across workgroups instead (fp32 partials summed in fixed
+ * order by the last workgroup to arrive: deterministic; sums agree with the no-workspace route to fp32 rounding, not bit for
+ * bit).  workspace == NULL or too small: exactly awq_gemm_repacked.  awq_gemm_repacked_workspace_bytes returns 0 where the
+ * scratch would not be used.
+ */
+size_t awq_gemm_repacked_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t group_size, int dtype);
+
+int awq_gemm_repacked_ws(const void* x, int64_t ldx, const void* packed, const void* bias, void* y, void* workspace,
+                         size_t workspace_bytes, int64_t M, int64_t K, int64_t N, int64_t group_size, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,8 @@ EXPORTS = (
     "awq_repacked_bytes",
     "awq_repack",
     "awq_gemm_repacked",
+    "awq_gemm_repacked_workspace_bytes",
+    "awq_gemm_repacked_ws",
 )
 # include/awq_aux.h (decode-harness helpers, not part of the operator boundary)
 AUX_EXPORTS = ("awq_aux_add_rmsnorm", "awq_aux_decode_attention", "awq_aux_decode_attention_workspace_bytes",
@@ -77,6 +79,10 @@ def _bind(L):
     L.awq_repack.restype = ci
     L.awq_gemm_repacked.argtypes = [vp, i64, vp, vp, vp, i64, i64, i64, i64, ci, vp]
     L.awq_gemm_repacked.restype = ci
+    L.awq_gemm_repacked_workspace_bytes.argtypes = [i64, i64, i64, i64, ci]
+    L.awq_gemm_repacked_workspace_bytes.restype = ctypes.c_size_t
+    L.awq_gemm_repacked_ws.argtypes = [vp, i64, vp, vp, vp, vp, ctypes.c_size_t, i64, i64, i64, i64, ci, vp]
+    L.awq_gemm_repacked_ws.restype = ci
     L.awq_aux_add_rmsnorm.argtypes = [vp, vp, vp, vp, i64, i64, ctypes.c_float, vp]
     L.awq_aux_add_rmsnorm.restype = ci
     L.awq_aux_decode_attention.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, ctypes.c_float, ci, vp, sz, vp]

@@ -34,6 +34,10 @@ static int repacked_dispatch(const GemmArgs& a, const void* packed) {
   // chip better (11008 x 4096 at M = 256: 142 -> 90 us); beyond that the hand-pipelined wide tiles.
   static const int env_mid = getenv("AWQ_MID") ? atoi(getenv("AWQ_MID")) : 1;      // A/B knob: 0 = never the 128 x 64 tiles
   if (M <= 32) {
+    if (M > 8 && a.workspace != nullptr) {             // narrow matrix, many rows: wide strips with K split across workgroups
+      const int rs = launch_gemv_repacked_splitk(a, packed);
+      if (rs != AWQ_ERR_BAD_VARIANT) return rs;
+    }
     const int rc = launch_gemv_repacked(a, packed);
     if (rc != AWQ_ERR_BAD_VARIANT || M <= 16) return rc;
     // 17..32 rows on a strip whose two-row-tile reduction scratch does not fit the CU's LDS: two passes of <= 16 rows
@@ -188,8 +192,18 @@ int awq_repack(const int32_t* qweight, const void* scales, const int32_t* qzeros
   return launch_repack(qweight, scales, qzeros, packed, K, N, group_size, dtype, (hipStream_t)stream);
 }
 
+size_t awq_gemm_repacked_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t group_size, int dtype) {
+  if (!repacked_fast(K, N, group_size, dtype)) return 0;
+  return rps_workspace_bytes(M, K, N);
+}
+
 int awq_gemm_repacked(const void* x, int64_t ldx, const void* packed, const void* bias, void* y, int64_t M, int64_t K,
                       int64_t N, int64_t group_size, int dtype, void* stream) {
+  return awq_gemm_repacked_ws(x, ldx, packed, bias, y, nullptr, 0, M, K, N, group_size, dtype, stream);
+}
+
+int awq_gemm_repacked_ws(const void* x, int64_t ldx, const void* packed, const void* bias, void* y, void* workspace,
+                         size_t workspace_bytes, int64_t M, int64_t K, int64_t N, int64_t group_size, int dtype, void* stream) {
   if (!packed) return AWQ_ERR_NULL_POINTER;
   if (K <= 0 || N <= 0 || group_size <= 0 || N % 8 || K % group_size || M < 0 || ldx < K) return AWQ_ERR_BAD_SHAPE;
   if (M == 0) return AWQ_OK;
@@ -199,7 +213,7 @@ int awq_gemm_repacked(const void* x, int64_t ldx, const void* packed, const void
   if (!repacked_supported(K, N, group_size, dtype) || M > INT32_MAX / 2) return AWQ_ERR_BAD_VARIANT;
   GemmArgs a;
   a.x = x; a.ldx = ldx; a.qweight = nullptr; a.scales = nullptr; a.qzeros = nullptr; a.bias = bias; a.y = y;
-  a.workspace = nullptr; a.workspace_bytes = 0;
+  a.workspace = workspace; a.workspace_bytes = workspace ? workspace_bytes : 0;      // optional: only the split-K route for 9..32 rows uses it
   a.M = (int)M; a.K = (int)K; a.N = (int)N; a.g = (int)group_size; a.dtype = dtype; a.tune = 0;
   a.stream = (hipStream_t)stream;
   return repacked_dispatch(a, packed);

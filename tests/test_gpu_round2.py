@@ -423,3 +423,48 @@ def test_gemv_ab_knobs_give_a_correct_result_or_an_error(knobs):
     env = dict(os.environ, **knobs)
     res = subprocess.run([sys.executable, "-c", _KNOB_SNIPPET.format(root=root)], capture_output=True, text=True, env=env, timeout=600)
     assert res.returncode == 0 and "KNOBS_OK" in res.stdout, f"{knobs}: rc={res.returncode}\n{res.stdout[-2000:]}\n{res.stderr[-3000:]}"
+
+
+def test_split_k_gemv_on_deep_narrow_matrices_vs_oracle(ops):
+    """9 .. 32 rows on a deep, narrow matrix (K >= 8192, N <= 4096): `awq_gemm_repacked_ws` runs wide strips with K split across
+    workgroups (awq_repacked_splitk.hip; fp32 partials through the per-stream workspace, last workgroup to arrive adds them in slice
+    order).  Against the oracle; repeated calls are bit-identical (fixed summation order, counters left at zero); the no-workspace
+    entry point gives the same values to fp32 summation order; the route survives graph capture."""
+    import ctypes
+
+    lib = _lib.load()
+    for (M, K, N, g) in [(9, 8192, 1280, 128), (16, 11008, 4096, 128), (17, 8192, 4096, 128), (32, 11008, 4096, 128),
+                         (32, 8192, 1032, 128), (12, 8192, 2048, 8192)]:
+        assert lib.awq_gemm_repacked_workspace_bytes(M, K, N, g, 0) > 0
+        qw, s, qz = synth.make_awq_weights(K, N, g, "f16", "A", seed=M + K + N)
+        x = synth.make_activations(M, K, "f16", "A", seed=M + 7)
+        packed = ops.awq_repack(*[to_torch(t, DEV) for t in (qw, s, qz)])
+        xt = to_torch(x, DEV)
+        y1 = ops.awq_gemm_repacked(xt, packed, K, N, g)
+        y2 = ops.awq_gemm_repacked(xt, packed, K, N, g)
+        assert torch.equal(y1, y2), f"split-K M={M} K={K} N={N}: not run-to-run identical"
+        _, exact = c_oracle.gemm(x, qw, s, qz, want_exact=True)
+        assert_gemm_close(to_np(y1), exact, "f16", what=f"split-K M={M} K={K} N={N} g={g}")
+        # the entry point without scratch (one strip per workgroup): same values up to the order of the fp32 sums
+        y0 = torch.empty_like(y1)
+        rc = lib.awq_gemm_repacked(ctypes.c_void_p(xt.data_ptr()), K, ctypes.c_void_p(packed.data_ptr()), None, ctypes.c_void_p(y0.data_ptr()),
+                                   M, K, N, g, 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert_gemm_close(to_np(y0), exact, "f16", what=f"one-strip M={M} K={K} N={N}")
+        assert (y0 != y1).float().mean().item() < 0.02          # different summation order: a rounding flips here and there at most
+    # graph capture: the workspace of the capturing stream is allocated by the eager warm-up call
+    M, K, N, g = 24, 11008, 4096, 128
+    qw, s, qz = synth.make_awq_weights(K, N, g, "f16", "A", seed=5)
+    packed = ops.awq_repack(*[to_torch(t, DEV) for t in (qw, s, qz)])
+    xt = to_torch(synth.make_activations(M, K, "f16", "A", seed=6), DEV)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        want = ops.awq_gemm_repacked(xt, packed, K, N, g)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            got = ops.awq_gemm_repacked(xt, packed, K, N, g)
+        for _ in range(3):
+            graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)

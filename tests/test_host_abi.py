@@ -196,6 +196,15 @@ def test_repacked_entry_points_refuse_shapes_without_a_layout(lib):
     assert lib.awq_gemm_repacked(vp(p), 4096, vp(p), None, vp(p), 128, 4096, 4096, 128, 2, None) == -7      # fp32
     assert lib.awq_gemm_repacked(vp(p), 4096, vp(p), None, vp(p), 128, 4096, 4096, 16, 0, None) == -7       # g = 16
     assert lib.awq_gemm_repacked(None, 4096, vp(p), None, vp(p), 1, 4096, 4096, 128, 0, None) == -1
+    # the workspace variant validates the same way (nothing is launched: every call fails before the dispatch)
+    assert lib.awq_gemm_repacked_ws(vp(p), 4096, vp(p), None, vp(p), None, 0, 128, 4096, 4096, 16, 0, None) == -7
+    assert lib.awq_gemm_repacked_ws(None, 4096, vp(p), None, vp(p), None, 0, 1, 4096, 4096, 128, 0, None) == -1
+    # scratch is only ever wanted for 9 .. 32 rows of a supported fp16 layout on a narrow matrix
+    assert lib.awq_gemm_repacked_workspace_bytes(1, 11008, 4096, 128, 0) == 0
+    assert lib.awq_gemm_repacked_workspace_bytes(64, 11008, 4096, 128, 0) == 0
+    assert lib.awq_gemm_repacked_workspace_bytes(32, 11008, 4096, 128, 1) == 0
+    assert lib.awq_gemm_repacked_workspace_bytes(32, 4096, 22016, 128, 0) == 0
+    assert 0 < lib.awq_gemm_repacked_workspace_bytes(32, 11008, 4096, 128, 0) <= 4096 + (32 << 20)
     # the fused decode variants exist for fp16 with g % 128 == 0 only
     assert lib.awq_aux_gemv_repacked_fused(vp(p), 192, vp(p), vp(p), 1, 192, 64, 64, 0, None, None, None, None, 0.0, 1, None) == -7
     assert lib.awq_aux_gemv_repacked_fused(vp(p), 4096, vp(p), vp(p), 1, 4096, 4096, 64, 0, None, None, None, None, 0.0, 1, None) == -7

@@ -319,10 +319,14 @@ static int cmd_rgemm(int argc, char** argv) {
   CK(hipMalloc(&nw, (size_t)K * 2)); fill_scales(nw, (size_t)K, AWQ_DTYPE_F16, 0.5f, 1.5f);
   CK(hipMalloc(&hout, (size_t)M * K * 2));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  // optional scratch (the split-K route for 9..32 rows on narrow matrices): on unless KBENCH_WS=0
+  void* ws = nullptr;
+  const size_t ws_bytes = (getenv("KBENCH_WS") && atoi(getenv("KBENCH_WS")) == 0) ? 0 : awq_gemm_repacked_workspace_bytes(M, K, N, g, AWQ_DTYPE_F16);
+  if (ws_bytes) { CK(hipMalloc(&ws, ws_bytes)); CK(hipMemset(ws, 0, ws_bytes)); }
   auto launch = [&](int i) {
     int rc = fuse ? awq_aux_gemv_repacked_fused(x, K, packed[i % sets], y, M, K, N, g, AWQ_DTYPE_F16, (fuse & 1) ? x : nullptr, delta, nw, hout,
                                                 1e-5f, (fuse & 2) ? 1 : 0, st)
-                  : awq_gemm_repacked(x, K, packed[i % sets], nullptr, y, M, K, N, g, AWQ_DTYPE_F16, st);
+                  : awq_gemm_repacked_ws(x, K, packed[i % sets], nullptr, y, ws, ws_bytes, M, K, N, g, AWQ_DTYPE_F16, st);
     if (rc) { fprintf(stderr, "awq_gemm_repacked: %s\n", awq_hip_status_string(rc)); exit(1); }
   };
   for (int i = 0; i < 2 * sets; ++i) launch(i);
