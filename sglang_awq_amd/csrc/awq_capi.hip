@@ -34,10 +34,6 @@ static int repacked_dispatch(const GemmArgs& a, const void* packed) {
   // chip better (11008 x 4096 at M = 256: 142 -> 90 us); beyond that the hand-pipelined wide tiles.
   static const int env_mid = getenv("AWQ_MID") ? atoi(getenv("AWQ_MID")) : 1;      // A/B knob: 0 = never the 128 x 64 tiles
   if (M <= 32) {
-    if (M > 16) {                                      // wide matrix, 17 .. 32 rows: x through LDS once per workgroup
-      const int rr = launch_gemv_repacked_rows(a, packed);
-      if (rr != AWQ_ERR_BAD_VARIANT) return rr;
-    }
     if (M > 8 && a.workspace != nullptr) {             // narrow matrix, many rows: wide strips with K split across workgroups
       const int rs = launch_gemv_repacked_splitk(a, packed);
       if (rs != AWQ_ERR_BAD_VARIANT) return rs;

@@ -62,7 +62,6 @@ bool repacked_fast(int64_t K, int64_t N, int64_t g, int dtype);
 bool pipelined_addressable(const GemmArgs& a);                                 // spans fit the prefill kernel's 32-bit buffer offsets
 int launch_gemv_repacked_splitk(const GemmArgs& a, const void* packed);   // 9..32 rows on narrow matrices, K split across workgroups, needs a.workspace (awq_repacked_splitk.hip)
 size_t rps_workspace_bytes(int64_t M, int64_t K, int64_t N);
-int launch_gemv_repacked_rows(const GemmArgs& a, const void* packed);     // 17..32 rows on wide matrices, x through LDS once per workgroup (awq_repacked_rows.hip)
 int launch_gemv_repacked_ext(const GemmArgs& a, const void* packed);          // bf16 / small groups, M <= 16 (awq_repacked_ext.hip)
 int launch_gemm_repacked_tiled_ext(const GemmArgs& a, const void* packed);    // bf16 / small groups, large M
 int launch_repack(const int32_t* qweight, const void* scales, const int32_t* qzeros, void* packed, int64_t K, int64_t N, int64_t g,
