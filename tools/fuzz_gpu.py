@@ -46,6 +46,10 @@ def main():
         if packed is not None:
             y2 = ops.awq_gemm_repacked(xt, packed, K, N, g)
             assert_gemm_close(to_np(y2), exact, dt, what=what + " (repacked)")
+            if it % 3 == 0:                                   # bias epilogue: the rounded sum plus bias, rounded again (awq.py:449-450)
+                b = (torch.randn(N, device=DEV) * 0.5).to(xt.dtype)
+                yb = ops.awq_gemm_repacked(xt, packed, K, N, g, b)
+                assert torch.equal(yb, y2 + b), what + " (bias epilogue)"
             # strided rows
             xw = torch.zeros((M, K + 24), dtype=xt.dtype, device=DEV)
             xw[:, 8:8 + K] = xt
