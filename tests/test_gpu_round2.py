@@ -468,3 +468,16 @@ def test_split_k_gemv_on_deep_narrow_matrices_vs_oracle(ops):
             graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(got, want)
+
+
+def test_random_shapes_every_dispatch_route(ops):
+    """A seeded subset of tools/fuzz_gpu.py: random (M, K, N, group size, dtype) through the op, the repacked entry point, strided
+    rows and the bias epilogue, against the C oracle — GEMV, split-K, passes, K-split tiles, pipelined tiles, bf16 / small groups."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_gpu.py")
+    spec = importlib.util.spec_from_file_location("fuzz_gpu", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(60, 11, verbose=False) == 60

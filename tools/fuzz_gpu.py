@@ -15,9 +15,8 @@ from tests.util import assert_gemm_close, to_np, to_torch  # noqa: E402
 DEV = "cuda:0"
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+def run(cases: int, seed: int, verbose: bool = True) -> int:
+    rng = np.random.default_rng(seed)
     Ms = [1, 2, 3, 5, 8, 9, 13, 16, 17, 24, 31, 32, 33, 48, 64, 97, 130, 160, 161, 200, 256, 257, 300, 385, 520]
     done = 0
     for it in range(cases):
@@ -56,8 +55,13 @@ def main():
             y3 = ops.awq_gemm_repacked(xw[:, 8:8 + K], packed, K, N, g)
             assert torch.equal(y3, y2), what + " (strided x differs)"
         done += 1
-        if it % 10 == 0:
+        if verbose and it % 10 == 0:
             print(f"{it:4d} ok  {what}", flush=True)
+    return done
+
+
+def main():
+    done = run(int(sys.argv[1]) if len(sys.argv) > 1 else 120, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     print(f"FUZZ_OK {done} cases")
 
 
