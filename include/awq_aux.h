@@ -54,11 +54,23 @@ int awq_aux_gemv_repacked_fused(const void* x, int64_t ldx, const void* packed, 
  * multiple of 16) — and writes output row s of y [slots, N] (or [slots, N / 2] with silu_mul = 1: SiLU(gate) * up, experts
  * repacked from gate / up column-interleaved tensors as for awq_aux_gemv_repacked_fused).  slot_scale (may be NULL): the fp32 sum
  * of slot s is multiplied by slot_scale[s] before its one rounding — the routed weight, applied where the reference's fused MoE
- * kernel applies it (mul_routed_weight).  fp16, group_size % 128 == 0; AWQ_ERR_BAD_VARIANT otherwise.  expert_ids are not
- * range-checked on the device: the caller guarantees 0 <= id < number of experts. */
+ * kernel applies it (mul_routed_weight).  fp16, group_size % 128 == 0; AWQ_ERR_BAD_VARIANT otherwise.  An id outside
+ * [0, num_experts) marks a padded slot — the reference's routing writes -1 for the padded tokens of a graph batch
+ * (layers/moe/topk.py:705-712) — : its output row is zero-filled on the device and no weight is read (no host check, no sync). */
 int awq_aux_moe_gemv(const void* x, int64_t ldx, int x_div, const void* packed_experts, int64_t expert_stride_bytes,
-                     const int32_t* expert_ids, const float* slot_scale, void* y, int64_t slots, int64_t K, int64_t N,
-                     int64_t group_size, int dtype, int silu_mul, void* stream);
+                     int64_t num_experts, const int32_t* expert_ids, const float* slot_scale, void* y, int64_t slots, int64_t K,
+                     int64_t N, int64_t group_size, int dtype, int silu_mul, void* stream);
+
+/* The same step for batches of any size without a host synchronisation: the (token, expert) pairs are sorted by expert on the
+ * device and cut into blocks of 16 rows that never straddle two experts (what the reference's moe_align_block_size prepares for
+ * its fused MoE kernels, layers/moe/fused_moe_triton/moe_align_block_size.py).  Grid row b multiplies the activation rows of
+ * the pairs row_map[16 b .. 16 b + 15] (pair index p -> activation row p / x_div; -1 = padding, nothing is stored for it) with
+ * the repacked weight of expert block_expert[b] (< 0: unused block, skipped) and writes output row p of y [pairs, N] (or
+ * [pairs, N / 2] with silu_mul); slot_scale[p] as in awq_aux_moe_gemv.  One launch streams each active expert once per 16 of its
+ * rows.  fp16, group_size % 128 == 0, K >= 2048; AWQ_ERR_BAD_VARIANT otherwise. */
+int awq_aux_moe_gemv_blocks(const void* x, int64_t ldx, int x_div, const void* packed_experts, int64_t expert_stride_bytes,
+                            const int32_t* row_map, const int32_t* block_expert, int64_t num_blocks, const float* slot_scale,
+                            void* y, int64_t K, int64_t N, int64_t group_size, int dtype, int silu_mul, void* stream);
 
 #ifdef __cplusplus
 }

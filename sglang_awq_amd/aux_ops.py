@@ -31,18 +31,34 @@ _attn_ws = {}
 _attn_ws_retired = []
 
 
+_ATTN_WS_MIN = 1 << 20
+
+
 def _attention_workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
     """Scratch of the split-S attention (tickets + partials) per (device, stream): the tickets are live during a call, so two
-    streams of one device never share them.  Zero-filled once, every call leaves the tickets zero.  Allocate it outside graph
-    capture (the first, uncaptured call of a shape does)."""
+    streams of one device never share them.  Zero-filled once, every call leaves the tickets zero.  Never created during graph
+    capture (the memory would come from the graph's private pool and the zero-fill would be an un-run graph node): a miss while
+    capturing raises — warm up on the capture stream or call ops.prepare_stream_workspaces() first."""
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
     ws = _attn_ws.get(key)
     if ws is None or ws.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("sglang_awq_amd: split-S attention needs its per-stream scratch and the first call on this stream is "
+                               "inside a graph capture; warm up on the capture stream or call ops.prepare_stream_workspaces(stream)")
         if ws is not None:
             _attn_ws_retired.append(ws)          # a captured graph may still point at it
-        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        ws = torch.zeros(max(nbytes, _ATTN_WS_MIN), dtype=torch.uint8, device=dev)
         _attn_ws[key] = ws
     return ws
+
+
+def prepare_attention_workspace(dev: torch.device, stream: int, nbytes: int = _ATTN_WS_MIN) -> None:
+    key = (dev.index, stream)
+    ws = _attn_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            _attn_ws_retired.append(ws)
+        _attn_ws[key] = torch.zeros(max(nbytes, _ATTN_WS_MIN), dtype=torch.uint8, device=dev)
 
 
 def decode_attention(qkv: torch.Tensor, pos: torch.Tensor, cos_table: torch.Tensor, sin_table: torch.Tensor, k_cache: torch.Tensor,

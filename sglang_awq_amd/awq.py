@@ -129,6 +129,12 @@ class AWQLinearMethod(LinearMethodBase):
         layer.register_parameter("scales", scales)
 
     def process_weights_after_loading(self, layer: torch.nn.Module) -> None:
+        if getattr(layer, "awq_shape", None) is not None and layer.qweight.numel() == 0:
+            # SGLANG_AWQ_AMD_KEEP_CHECKPOINT=0 released the checkpoint tensors of this layer after the first re-layout: there is
+            # nothing left to re-derive the copy from, and nothing a weight loader could have written into
+            raise RuntimeError("sglang_awq_amd: this layer's checkpoint tensors were released (SGLANG_AWQ_AMD_KEEP_CHECKPOINT=0); "
+                               "weights cannot be reloaded in place. Run with SGLANG_AWQ_AMD_KEEP_CHECKPOINT=1 for deployments "
+                               "that update weights, or rebuild the layer (create_weights) before loading.")
         # the kernels consume the on-disk AutoAWQ layout directly: no repack (awq.py:429-432)
         layer.qweight = torch.nn.Parameter(layer.qweight.data, requires_grad=False)
         layer.qzeros = torch.nn.Parameter(layer.qzeros.data, requires_grad=False)
@@ -147,12 +153,29 @@ class AWQLinearMethod(LinearMethodBase):
                 # size runs on the repacked copy); releasing them halves the weight memory (70B at TP = 1: 35 GB).  The
                 # parameters stay registered with their shapes' metadata (`awq_shape`) but empty storage, so
                 # `sgl_kernel.awq_dequantize(layer.qweight, ...)` on such a layer raises instead of reading freed memory.
-                if layer.awq_packed is not None and os.environ.get("SGLANG_AWQ_AMD_KEEP_CHECKPOINT", "1") == "0":
+                if (layer.awq_packed is not None and os.environ.get("SGLANG_AWQ_AMD_KEEP_CHECKPOINT", "1") == "0"
+                        and self._every_batch_has_repacked_variant(layer)):
                     K, C = layer.qweight.shape
                     layer.awq_shape = (K, C * self.quant_config.pack_factor, K // layer.scales.shape[0])
                     for name in ("qweight", "qzeros", "scales"):
                         t = getattr(layer, name)
                         setattr(layer, name, torch.nn.Parameter(torch.empty(0, dtype=t.dtype, device=t.device), requires_grad=False))
+
+    def _every_batch_has_repacked_variant(self, layer) -> bool:
+        """Before the checkpoint tensors are released: run the repacked route once at every decode batch-size class and at a
+        prefill size, so a (K, N, g) for which one of them has no instantiation (AWQ_ERR_BAD_VARIANT — the route `apply` would
+        cover with the checkpoint-layout kernel) keeps its checkpoint tensors instead of failing at serving time."""
+        from . import ops
+
+        K = layer.qweight.shape[0]
+        N = layer.qweight.shape[1] * self.quant_config.pack_factor
+        g = K // layer.scales.shape[0]
+        try:
+            for m in (1, 8, 16, 17, 32, 64, 256):
+                ops.awq_gemm_repacked(torch.zeros((m, K), dtype=layer.scales.dtype, device=layer.qweight.device), layer.awq_packed, K, N, g)
+        except ops.AwqHipError:
+            return False
+        return True
 
     def apply(self, layer: torch.nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         from . import ops

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "../../include/awq_hip.h"
+#include "awq_device.h"
 
 namespace awq {
 
@@ -36,6 +37,9 @@ struct GemmArgs {
   int64_t moe_expert_stride = 0;     // bytes between the repacked weights of consecutive experts
   int moe_x_div = 1;                 // activation row of slot s = s / moe_x_div
   int moe_slots = 0;
+  int moe_num_experts = 0;           // ids outside [0, moe_num_experts) are padded slots: zero output rows
+  // optional: bytes the next kernel on the stream will read first (awq_hip.h: awq_next_hint); ptr == nullptr = none
+  NextHint next;
 };
 
 int launch_dequantize(const int32_t* qweight, const void* scales, const int32_t* qzeros, void* out, int64_t K,
@@ -67,6 +71,8 @@ int launch_gemm_repacked_tiled_ext(const GemmArgs& a, const void* packed);    //
 int launch_repack(const int32_t* qweight, const void* scales, const int32_t* qzeros, void* packed, int64_t K, int64_t N, int64_t g,
                   int dtype, hipStream_t stream);
 int launch_gemv_repacked(const GemmArgs& a, const void* packed);
+bool gemv_strip_geometry(int64_t K, int64_t N, int* G, int* nwg);          // strip width / workgroups of the one-strip-per-workgroup decode GEMV; false: rounds mode
+int launch_gemv_repacked_loop(const GemmArgs& a, const void* packed);    // loop form of the straight-line GEMV: deep K, 9..16 rows on deep matrices (awq_repacked_loop.hip)
 int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed);   // norm prologue and / or SiLU-mul epilogue (awq_repacked_fused.hip)
 int launch_gemv_repacked_moe(const GemmArgs& a, const void* packed);     // expert-indirect M = 1 GEMVs, one grid row per (token, expert) slot
 int launch_gemm_repacked_tiled(const GemmArgs& a, const void* packed);   // any M, MFMA-bound prefill shapes

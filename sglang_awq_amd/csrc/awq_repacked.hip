@@ -175,6 +175,17 @@ extern "C" void awq_debug_set_stamp_buffer(void* p) { g_rp_stamp_buffer = (unsig
 
 static int rp_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
+bool gemv_strip_geometry(int64_t K, int64_t N, int* G, int* nwg) {
+  (void)K;
+  const int NG = rp_groups(N);
+  int g = (NG + 255) / 256;
+  if (g > kRpMaxG) return false;
+  if (g > NG) g = NG;
+  *G = g;
+  *nwg = (NG + g - 1) / g;
+  return true;
+}
+
 int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
   if (!repacked_supported(a.K, a.N, a.g, a.dtype) || a.M < 1 || a.M > 16 * kRpMaxMT || a.ldx % 8 || (((uintptr_t)a.x) & 15)) return AWQ_ERR_BAD_VARIANT;
   if (!repacked_fast(a.K, a.N, a.g, a.dtype)) {           // bf16 / g in {32, 64}: the generic kernel, 16 rows per launch
@@ -234,6 +245,14 @@ int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
   if (env_rp2 && !two_tiles && env_t != 0 && ((W == 16 && nt) || rp2_small)) {
     const int depth = env_d >= 0 ? env_d : 2;
     if (rp2_launch<0>(G, (KB + 15) / 16, a, packed, NG, depth, nwg)) return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+  }
+  // what the straight-line form cannot hold (more than 8 staging chunks per lane: many rows on a deep matrix; more than 16 units per
+  // wave: deep K, wide strips) runs its loop form, gemv_rp3_kernel (awq_repacked_loop.hip): same ring, x / zs staged per stage.
+  // AWQ_RP3=0: the round-1 loop kernel instead (A/B)
+  static const int env_rp3 = rp_env("AWQ_RP3", 1);
+  if (env_rp3 && !two_tiles && !rounds && KB >= 16 && env_t != 0 && env_waves == 0 && env_g == 0) {
+    const int rc = launch_gemv_repacked_loop(a, packed);
+    if (rc != AWQ_ERR_BAD_VARIANT) return rc;
   }
   if (W == 16 && env_waves != 16 && (T < 0 || (T == 0 && (KB + 15) / 16 <= 6))) {   // straight-line did not fit: 8 waves measured better than the 16-wave loop
     W = 8;

@@ -106,10 +106,12 @@ int launch_gemv_repacked_moe(const GemmArgs& a, const void* packed) {
 }  // namespace awq
 
 extern "C" int awq_aux_moe_gemv(const void* x, int64_t ldx, int x_div, const void* packed_experts, int64_t expert_stride_bytes,
-                                const int32_t* expert_ids, const float* slot_scale, void* y, int64_t slots, int64_t K, int64_t N,
-                                int64_t group_size, int dtype, int silu_mul, void* stream) {
+                                int64_t num_experts, const int32_t* expert_ids, const float* slot_scale, void* y, int64_t slots,
+                                int64_t K, int64_t N, int64_t group_size, int dtype, int silu_mul, void* stream) {
   if (!x || !packed_experts || !expert_ids || !y) return AWQ_ERR_NULL_POINTER;
-  if (K <= 0 || N <= 0 || group_size <= 0 || N % 8 || K % group_size || slots <= 0 || ldx < K || x_div < 1) return AWQ_ERR_BAD_SHAPE;
+  if (K <= 0 || N <= 0 || group_size <= 0 || N % 8 || K % group_size || slots <= 0 || ldx < K || x_div < 1 || num_experts < 1 ||
+      num_experts > INT32_MAX)
+    return AWQ_ERR_BAD_SHAPE;
   if ((((uintptr_t)packed_experts) & 15) || (((uintptr_t)y) & 1)) return AWQ_ERR_MISALIGNED;
   awq::GemmArgs a;
   a.x = x; a.ldx = ldx; a.qweight = nullptr; a.scales = nullptr; a.qzeros = nullptr; a.bias = nullptr; a.y = y;
@@ -119,6 +121,7 @@ extern "C" int awq_aux_moe_gemv(const void* x, int64_t ldx, int x_div, const voi
   a.silu_mul = silu_mul;
   a.moe_expert_ids = expert_ids; a.moe_slot_scale = slot_scale; a.moe_expert_stride = expert_stride_bytes; a.moe_x_div = x_div;
   a.moe_slots = (int)slots;
+  a.moe_num_experts = (int)num_experts;
   return awq::launch_gemv_repacked_moe(a, packed_experts);
 }
 

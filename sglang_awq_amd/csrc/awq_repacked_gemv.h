@@ -95,6 +95,9 @@ struct RpFuse {
   const float* slot_scale;
   long long expert_stride;
   int x_div;
+  int num_experts;             // ids outside [0, num_experts) mark padded slots (the reference writes -1 for the padded tokens of a
+                               // graph batch, layers/moe/topk.py:705-712): their output row is zero-filled, no weight is read
+  NextHint next;               // bytes the next kernel on the stream reads first (gemv_rp2_kernel only; ptr == nullptr: none)
 };
 
 // T = k-blocks per wave when it is small enough to issue every load up front (straight-line code, exact
@@ -326,8 +329,14 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
 // sums by inv_rms = rsqrt(sum(v^2) / K + eps) before the one rounding to fp16.  Against the eager order
 // fp16(fp16(v * inv) * w) this moves where x is rounded (by at most an fp16 ulp of x per element; the tests restate this
 // order in the oracle and bound the distance to the eager order); workgroup 0 stores v = h + delta (fp16 add, bit-exact).
+// x' is staged as v * (w / 64) and the epilogue multiplies by 64 inv_rms: exact (powers of two) wherever v w and w / 64 are normal
+// fp16 numbers, and finite for |v w| up to 4e6 — residual streams with massive activations (1e3..1e4 in a few channels of
+// Llama-family models) times a norm weight above 1 would overflow the un-scaled product.
 // The earlier norm prologue (gemv_repacked_kernel, PRO > 0) needed every workgroup to re-read all of h + delta and one
 // workgroup barrier before its weight loads: +1.6 us at M = 1, +6.5 at M = 8; this form costs two extra staging loads.
+#ifndef RP2_CMAJOR
+#define RP2_CMAJOR 1          // unit i = (c = i / T, t = i % T): a wave's consecutive loads are contiguous, and the first third of what a
+#endif                        // workgroup asks for is column group 0 of its strip (what a next-weights hint covers); 0: t-major (round 2)
 #ifndef RP2_EARLY
 #define RP2_EARLY 1           // 0: A/B build, the replacement load is issued behind the unit's compute (round-2 first form)
 #endif
@@ -352,7 +361,16 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
   float slot_scale = 1.f;
   if (fz.expert_ids != nullptr) {                        // AWQ-MoE: one (token, expert) pair per grid row (wave-uniform)
     const int slot = blockIdx.y;
-    const long long eoff = (long long)fz.expert_ids[slot] * fz.expert_stride;
+    const int eid = fz.expert_ids[slot];
+    if (eid < 0 || eid >= fz.num_experts) {             // padded slot (uniform over the workgroup: no barrier is left half-entered)
+      const int width = EPI == 1 ? N / 2 : N, per = EPI == 1 ? 8 * G : 16 * G;
+      const int n0 = EPI == 1 ? (cg0 / 2) * 16 : cg0 * 16;
+      half_t* yr = (half_t*)y + (size_t)slot * width;
+      for (int i = threadIdx.x; i < per; i += W * 64)
+        if (n0 + i < width) yr[n0 + i] = (half_t)0.f;
+      return;
+    }
+    const long long eoff = (long long)eid * fz.expert_stride;
     qw_r = (const u32x4_t*)((const unsigned char*)qw_r + eoff);
     zs_r = (const uint32_t*)((const unsigned char*)zs_r + eoff);
     x += (size_t)(slot / fz.x_div) * ldx;
@@ -438,11 +456,21 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
   constexpr int RB = (RP2_EARLY && M1 && DD < L) ? DD + 1 : DD;      // (one-row form only: at M = 4 / 16 it measured 1 % slower, at M = 1 0-3 % faster)
   u32x4_t wbuf[RB];
   auto load_w = [&](int i) {
-    const int t = i / G, c = i - t * G;
+    const int t = RP2_CMAJOR ? i % T : i / G, c = RP2_CMAJOR ? i / T : i - t * G;
     int kb = kb0 + t;
     kb = kb < KB ? kb : KB - 1;
     const unsigned char* p = (const unsigned char*)(qw_r + ((size_t)(cg0 + c) * KB + kb) * 64) + loff;
     wbuf[i % RB] = __builtin_nontemporal_load((const u32x4_t*)p);      // streamed once: keep it out of the caches' way
+  };
+  // next-weights hint: touched right behind this wave's LAST own weight load, so the CU's memory queue never runs dry between the
+  // end of this kernel's stream and the start of the next one's
+  uint32_t nk0 = 0, nk1 = 0;
+  const bool touches = fz.next.ptr != nullptr && wave >= fz.next.wave_min;       // wave-uniform
+  auto touch_next = [&]() {
+    if (touches) {
+      const int tw = W - fz.next.wave_min;
+      next_touch(fz.next, ((int)(blockIdx.y * gridDim.x + blockIdx.x)) * tw + (wave - fz.next.wave_min), lane, nk0, nk1);
+    }
   };
 #pragma unroll
   for (int i = 0; i < DD; ++i) {
@@ -450,6 +478,7 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
     if (D != 0 && i < 2) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
   }
   __builtin_amdgcn_sched_barrier(0);
+  if (DD >= L) { touch_next(); __builtin_amdgcn_sched_barrier(0); }
   if constexpr (NORM) {
 #pragma unroll
     for (int i = 0; i < CHS; ++i) {
@@ -457,7 +486,10 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
       const int row = id / (T * 16), cc = id - row * (T * 16);
       const h8_t v = nh[i] + nd[i];                                      // fp16 add, as the eager h = h + delta
       if (blockIdx.x == 0 && nin[i]) *(h8_t*)(fz.h_out + (size_t)row * ldx + (size_t)kb0 * 128 + cc * 8) = v;
-      sv[i] = __builtin_bit_cast(u32x4_t, v * nw[i]);                    // x' = v * w (fp16 product); inv_rms comes in the epilogue
+      // x' = v * (w / 64) (fp16 products; the power-of-two pre-scale is exact and keeps |x'| inside fp16 for residual streams with
+      // massive activations: |v w| up to 4e6 instead of 65504); inv_rms * 64 comes in the epilogue
+      const h8_t wsc = nw[i] * (half_t)0.015625f;
+      sv[i] = __builtin_bit_cast(u32x4_t, v * wsc);
       float ss = 0.f;
       if (nin[i]) {
 #pragma unroll
@@ -499,8 +531,8 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
   u32x4_t xa[4];
 #pragma unroll
   for (int i = 0; i < L; ++i) {
-    const int t = i / G, c = i - t * G;
-    if (c == 0) {
+    const int t = RP2_CMAJOR ? i % T : i / G, c = RP2_CMAJOR ? i / T : i - t * G;
+    if (RP2_CMAJOR ? (T > 1 || i == 0) : c == 0) {
 #pragma unroll
       for (int d = 0; d < 4; ++d) xa[d] = *(const u32x4_t*)(x_lds + t * 128 + d * 32 + q * 8);
     }
@@ -513,6 +545,7 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
       asm volatile("" : "+v"(w));                        // unit i has arrived (the wait sits here) ...
       __builtin_amdgcn_sched_barrier(0);
       load_w(i + DD);                                    // ... its replacement leaves at once, into the spare register set
+      if (i + DD == L - 1) touch_next();
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -528,6 +561,7 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
     __builtin_amdgcn_sched_barrier(0);
     if (RB == DD && i + DD < L) {
       load_w(i + DD);
+      if (i + DD == L - 1) touch_next();
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -557,7 +591,7 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
       float tot = 0.f;
       for (int w = 0; w < W; ++w)
         for (int t = 0; t < T; ++t) tot += norm_part[((size_t)w * M + threadIdx.x) * T + t];      // fixed order
-      inv_rms[threadIdx.x] = __builtin_amdgcn_rsqf(tot / (float)K + fz.eps);
+      inv_rms[threadIdx.x] = __builtin_amdgcn_rsqf(tot / (float)K + fz.eps) * 64.f;       // (undoes the staging pre-scale)
     }
     __syncthreads();
   }
@@ -594,6 +628,7 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
       store_output<AWQ_DTYPE_F16>(y, (size_t)m * N + n, v, bias, n);
     }
   }
+  if (touches) next_touch_wait(nk0, nk1);
 }
 
 // rp2 exists for T <= 8, G <= 8, G T <= 16 (unrolled length), staging of <= 8 chunks per lane; returns false when the
@@ -616,8 +651,16 @@ static bool rp2_launch_t(const GemmArgs& a, const void* packed, int NG, int chun
     int lg = 0;
     while ((1 << lg) < gk) ++lg;
     const int gshift = 12 + lg, gmul = (int)(((1ll << gshift) + gk - 1) / gk);
+    NextHint nh = a.next;                                 // sized to this launch's grid: one or two lines of 64 B per touching lane
+    if (nh.ptr != nullptr) {
+      if (nh.wave_min < 0 || nh.wave_min > 15 || nh.span <= 0 || (nh.span & 63) || nh.regions <= 0) nh = NextHint();
+      else {
+        const long long slots = (long long)nwg * (a.moe_slots > 0 ? a.moe_slots : 1) * (16 - nh.wave_min);
+        nh.passes = (long long)nh.regions * (nh.span >> 6) > slots * 64 ? 2 : 1;
+      }
+    }
     const RpFuse fz = {(const half_t*)a.norm_h, (const half_t*)a.norm_delta, (const half_t*)a.norm_w, (half_t*)a.norm_h_out, a.norm_eps,
-                      a.moe_expert_ids, a.moe_slot_scale, (long long)a.moe_expert_stride, a.moe_x_div};
+                      a.moe_expert_ids, a.moe_slot_scale, (long long)a.moe_expert_stride, a.moe_x_div, a.moe_num_experts, nh};
 #define RP2_GO(CHS, DEP, ONE, NRM)                                                                                                 \
     do {                                                                                                                           \
       auto kern = gemv_rp2_kernel<G, T, CHS, DEP, EPI, ONE, NRM>;                                                                  \
@@ -723,7 +766,7 @@ static bool rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wav
   const u32x4_t* qw_r = (const u32x4_t*)packed;
   const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
   const RpFuse fz = {(const half_t*)a.norm_h, (const half_t*)a.norm_delta, (const half_t*)a.norm_w, (half_t*)a.norm_h_out, a.norm_eps,
-                      a.moe_expert_ids, a.moe_slot_scale, (long long)a.moe_expert_stride, a.moe_x_div};
+                      a.moe_expert_ids, a.moe_slot_scale, (long long)a.moe_expert_stride, a.moe_x_div, a.moe_num_experts, NextHint()};
   dim3 grid(nwg), block(W * 64);
 #define RP_GO(TT)                                                                                                                     \
   if constexpr ((PRO == 0 && EPI == 0) ? (TT <= 6 && rp_fits(W, MT, G, TT) && (MT == 1 || TT == 0 || TT == 4))                           \

@@ -62,9 +62,13 @@ class LinearBase(torch.nn.Module):
         else:
             self.quant_method = quant_config.get_quant_method(self, prefix=prefix)
 
-    def _make_bias(self, size: int, bias: bool):
+    def _make_bias(self, size: int, bias: bool, weight_loader=None):
+        """The reference gives `bias` a weight_loader and `output_dim: 0` (linear.py:348-358, 1286-1293): a column-parallel
+        bias is sharded along the output dim like its weight (per logical matrix for merged / QKV layers), a row-parallel bias
+        is replicated (and added on rank 0 only, linear.py:1401)."""
         if bias:
-            self.bias = Parameter(torch.zeros(size, dtype=self.params_dtype), requires_grad=False)
+            self.bias = ShardedParameter(torch.zeros(size, dtype=self.params_dtype), input_dim=0, output_dim=0,
+                                         weight_loader=weight_loader)
         else:
             self.register_parameter("bias", None)
 
@@ -77,7 +81,7 @@ class ReplicatedLinear(LinearBase):
         super().__init__(input_size, output_size, skip_bias_add, params_dtype, quant_config, prefix)
         self.quant_method.create_weights(self, input_size, [output_size], input_size, output_size, self.params_dtype,
                                          weight_loader=self.weight_loader_v2)
-        self._make_bias(output_size, bias)
+        self._make_bias(output_size, bias, self.weight_loader_v2)
 
     def weight_loader_v2(self, param: ShardedParameter, loaded_weight: torch.Tensor):
         param.load_column_parallel_weight(loaded_weight, tp_rank=0, use_presharded_weights=True)
@@ -103,7 +107,7 @@ class ColumnParallelLinear(LinearBase):
             self.output_partition_sizes = [divide(s, self.tp_size) for s in self.output_sizes]
         self.quant_method.create_weights(self, self.input_size, self.output_partition_sizes, self.input_size,
                                          self.output_size, self.params_dtype, weight_loader=self.weight_loader_v2)
-        self._make_bias(self.output_size_per_partition, bias)
+        self._make_bias(self.output_size_per_partition, bias, self.weight_loader_v2)
 
     def weight_loader_v2(self, param: ShardedParameter, loaded_weight: torch.Tensor):
         param.load_column_parallel_weight(loaded_weight, tp_rank=self.tp_rank,
@@ -219,11 +223,17 @@ class RowParallelLinear(LinearBase):
                                          self.output_size, self.params_dtype, weight_loader=self.weight_loader_v2)
         if not reduce_results and bias and not skip_bias_add:
             raise ValueError("When not reduce the results, adding bias to the results can lead to incorrect results")
-        self._make_bias(self.output_size, bias)
+        self._make_bias(self.output_size, bias, self._load_replicated_bias)
 
     def weight_loader_v2(self, param: ShardedParameter, loaded_weight: torch.Tensor):
         param.load_row_parallel_weight(loaded_weight, tp_rank=self.tp_rank,
                                        use_presharded_weights=self.use_presharded_weights)
+
+    @staticmethod
+    def _load_replicated_bias(param: ShardedParameter, loaded_weight: torch.Tensor):
+        """The bias of a row-parallel layer has no input dim to split: every rank holds all of it (the reference's v1
+        weight_loader with input_dim = None, linear.py:1296-1340) and rank 0 alone adds it."""
+        param.load_column_parallel_weight(loaded_weight, tp_rank=0, use_presharded_weights=True)
 
     def forward(self, input_, skip_all_reduce: bool = False):
         if self.input_is_parallel:

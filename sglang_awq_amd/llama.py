@@ -36,6 +36,9 @@ class LlamaConfig:
     rms_norm_eps: float = 1e-5
     rope_theta: float = 10000.0
     max_position_embeddings: int = 4096
+    qkv_bias: bool = False          # Qwen2-style checkpoints carry q/k/v biases; HF Llama's `attention_bias` sets qkv + o
+    o_bias: bool = False
+    mlp_bias: bool = False
 
     @property
     def head_dim(self) -> int:
@@ -75,12 +78,12 @@ class LlamaDecoderLayer(torch.nn.Module):
         self.kv_size = self.num_kv_heads * self.head_dim
         p = f"model.layers.{layer_id}"
         self.qkv_proj = QKVParallelLinear(cfg.hidden_size, self.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads,
-                                          bias=False, quant_config=quant, params_dtype=dtype, prefix=f"{p}.self_attn.qkv_proj")
-        self.o_proj = RowParallelLinear(cfg.num_attention_heads * self.head_dim, cfg.hidden_size, bias=False,
+                                          bias=cfg.qkv_bias, quant_config=quant, params_dtype=dtype, prefix=f"{p}.self_attn.qkv_proj")
+        self.o_proj = RowParallelLinear(cfg.num_attention_heads * self.head_dim, cfg.hidden_size, bias=cfg.o_bias,
                                         quant_config=quant, params_dtype=dtype, prefix=f"{p}.self_attn.o_proj")
-        self.gate_up_proj = MergedColumnParallelLinear(cfg.hidden_size, [cfg.intermediate_size] * 2, bias=False,
+        self.gate_up_proj = MergedColumnParallelLinear(cfg.hidden_size, [cfg.intermediate_size] * 2, bias=cfg.mlp_bias,
                                                        quant_config=quant, params_dtype=dtype, prefix=f"{p}.mlp.gate_up_proj")
-        self.down_proj = RowParallelLinear(cfg.intermediate_size, cfg.hidden_size, bias=False, quant_config=quant,
+        self.down_proj = RowParallelLinear(cfg.intermediate_size, cfg.hidden_size, bias=cfg.mlp_bias, quant_config=quant,
                                            params_dtype=dtype, prefix=f"{p}.mlp.down_proj")
         self.input_layernorm = torch.nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype), requires_grad=False)
         self.post_attention_layernorm = torch.nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype), requires_grad=False)
@@ -299,7 +302,9 @@ class GraphedDecoder:
         torch.cuda.current_stream().wait_stream(s)
         graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):     # (the RCCL watchdog thread may touch the runtime meanwhile)
+            # capture on the SAME stream the warm-up steps ran on: the per-(device, stream) scratch buffers of the split-K GEMV
+            # and the split-S attention already exist there (a capture-time miss raises instead of allocating, ops._workspace)
+            with torch.cuda.graph(graph, stream=s, capture_error_mode="thread_local"):     # (the RCCL watchdog thread may touch the runtime meanwhile)
                 self._step()
             self.graph = graph
         except Exception as e:       # e.g. a collective that cannot be captured on this stack: run() then steps eagerly

@@ -8,7 +8,8 @@ What the reference does, restated for a local model directory (there is no netwo
     (`model.layers.N.self_attn.q_proj.qweight|qzeros|scales`, ...), opened with safetensors (no pickle);
   * stacked parameters: q/k/v -> `qkv_proj` shards "q"/"k"/"v", gate/up -> `gate_up_proj` shards 0/1
     (models/llama.py:560-632); each parameter's `weight_loader` does the tensor-parallel slicing
-    (parameter.py, linear.py `weight_loader_v2`);
+    (parameter.py, linear.py `weight_loader_v2`); `*.bias` tensors go the same way (a q/k/v bias is a shard of
+    `qkv_proj.bias`, column-sharded; an o_proj / down_proj bias is replicated: linear.py:348-358, 1286-1293);
   * afterwards `process_weights_after_loading` on every linear (model_loader/loader.py:616-632).
 """
 from __future__ import annotations
@@ -59,7 +60,11 @@ def load_llama_config(model_dir: str) -> LlamaConfig:
                        num_hidden_layers=hf["num_hidden_layers"], num_attention_heads=hf["num_attention_heads"],
                        num_key_value_heads=hf.get("num_key_value_heads", hf["num_attention_heads"]), vocab_size=hf["vocab_size"],
                        rms_norm_eps=hf.get("rms_norm_eps", 1e-5), rope_theta=hf.get("rope_theta", 10000.0),
-                       max_position_embeddings=hf.get("max_position_embeddings", 4096))
+                       max_position_embeddings=hf.get("max_position_embeddings", 4096),
+                       # HF Llama: attention_bias covers q/k/v/o, mlp_bias gate/up/down; Qwen2 always has q/k/v biases
+                       qkv_bias=bool(hf.get("attention_bias", False)) or hf.get("model_type") == "qwen2",
+                       o_bias=bool(hf.get("attention_bias", False)) and hf.get("model_type") != "qwen2",
+                       mlp_bias=bool(hf.get("mlp_bias", False)))
 
 
 def iterate_safetensors(model_dir: str) -> Iterator[Tuple[str, torch.Tensor]]:
@@ -97,7 +102,7 @@ def load_weights(model: LlamaForCausalLM, weights: Iterable[Tuple[str, torch.Ten
                 continue
             name = _module_param_name(ckpt_name.replace(weight_part, param_part))
             if name not in params:
-                stats["skipped"] += 1          # e.g. an extra bias of a GPTQ-style export
+                stats["skipped"] += 1          # the layer was built without that parameter (e.g. bias=False in the config)
                 break
             p = params[name]
             p.weight_loader(p, tensor, shard_id)

@@ -2,27 +2,36 @@
 
 Counterpart of `AWQMoEMethod` in the reference (python/sglang/srt/layers/quantization/awq.py:661-852): same parameter
 names and shapes (`w13_qweight [E, K, 2I/8]`, `w2_qweight [E, I, K/8]`, `w13_scales [E, K/g, 2I]`, `w2_scales [E, I/g, K]`,
-`w13_qzeros`, `w2_qzeros`), created by `create_weights`, consumed after `process_weights_after_loading`.  The reference
-re-lays the experts out for NVIDIA's Marlin MoE kernels (`awq_marlin_moe_repack`, awq.py:760-815) and runs
+`w13_qzeros`, `w2_qzeros`), created by `create_weights`, consumed after `process_weights_after_loading`, and the same call
+interface: `create_moe_runner(layer, moe_runner_config)` then `apply(layer, dispatch_output) -> CombineInput`
+(awq.py:815-845), with `dispatch_output.hidden_states` / `dispatch_output.topk_output.{topk_weights, topk_ids}` read by
+attribute (StandardDispatchOutput / StandardTopKOutput, layers/moe/token_dispatcher/standard.py:53-61, layers/moe/topk.py:161-166)
+and a `StandardCombineInput`-shaped result (`.hidden_states`, standard.py:68-76) — so the reference's `FusedMoE` layer can call
+it.  The reference re-lays the experts out for NVIDIA's Marlin MoE kernels (`awq_marlin_moe_repack`, awq.py:760-815) and runs
 `fused_marlin_moe`; on ROCm it has no native path ("HIP does not support fused_marlin_moe currently", awq.py:70) and AWQ
-experts go through the Triton kernels of `moe_wna16.py`.  Here every expert gets the MFMA-fragment-major copy of the dense
-path (`awq_repack`; w13 from gate / up column-interleaved tensors so SiLU·mul is the GEMV's epilogue), and a forward is
+experts go through the Triton kernels of `moe_wna16.py` after converting the AWQ nibble order (moe_wna16.py:390-412).  Here
+every expert gets the MFMA-fragment-major copy of the dense path (`awq_repack` reads the AWQ order directly; w13 from gate / up
+column-interleaved tensors so SiLU·mul is the GEMV's epilogue), and a forward is, without any host synchronisation
+(graph-capturable at every size):
 
-    decode-sized batches (tokens x top_k <= MOE_GEMV_MAX_SLOTS): two launches — `awq_aux_moe_gemv` over the (token, expert)
-        pairs with the SiLU·mul epilogue, then again for w2 with the routed weight applied to the fp32 sums — and one sum
-        over the top_k partial rows (graph-capturable: no host synchronisation, expert ids stay on the device);
-    larger batches: tokens grouped by expert on the host (one synchronisation), one fused dense call per active expert.
+    few pairs (tokens x top_k <= MOE_SLOT_MAX_PAIRS): two launches of `awq_aux_moe_gemv` over the (token, expert) pairs, one
+        grid row per pair — w13 with the SiLU·mul epilogue, w2 with the routed weight applied to the fp32 sums;
+    more pairs: the pairs are sorted by expert ON THE DEVICE and cut into 16-row blocks that never straddle two experts (the
+        reference's moe_align_block_size step), then two launches of `awq_aux_moe_gemv_blocks` — one expert stream per 16 rows
+        instead of one per pair, same epilogues, same rounding points;
+    then one sum over each token's top_k rows.  Ids outside [0, E) (the reference marks the padded tokens of a graph batch
+    with -1, layers/moe/topk.py:705-712) contribute zero.
 
 Arithmetic (what the reference's fused MoE computes, fused_moe.py fused_experts_impl): per (token, expert) pair
 act = fp16(silu(fp16 gate)) * fp16 up of the fp16-rounded w13 output, y = fp16(routed weight * fp32 sums of act @ W2),
-output = fp16(sum over the token's pairs).  No fixture of the reference pins MoE outputs (its only AWQ-MoE tests are e2e
-accuracy runs, test/srt/quant/test_awq.py:15-44): the tests compare against the oracle's dense linear composed in numpy —
-**parity unpinned** beyond the dense path's pin.
+output = fp16(sum over the token's pairs) (* routed_scaling_factor if the runner config carries one).  No fixture of the
+reference pins MoE outputs (its only AWQ-MoE tests are e2e accuracy runs, test/srt/quant/test_awq.py:15-44): the tests compare
+against the oracle's dense linear composed in numpy — **parity unpinned** beyond the dense path's pin.
 """
 from __future__ import annotations
 
 import ctypes
-from typing import Optional
+from typing import NamedTuple, Optional
 
 import torch
 
@@ -39,15 +48,39 @@ def select_experts(router_logits: torch.Tensor, top_k: int, renormalize: bool = 
     return topk_weights, topk_ids.to(torch.int32)
 
 
-class AWQMoEMethod:
-    """create_weights / process_weights_after_loading / apply for a layer of AWQ-quantised experts."""
+class StandardCombineInput(NamedTuple):
+    """What `apply` returns: the reference's StandardCombineInput (layers/moe/token_dispatcher/standard.py:68-76)."""
 
-    MOE_GEMV_MAX_SLOTS = 64          # (token, expert) pairs served by the one-row-per-slot launch; beyond: grouped by expert
+    hidden_states: torch.Tensor
+
+    @property
+    def format(self) -> str:
+        return "standard"
+
+
+class AWQMoEMethod:
+    """create_weights / process_weights_after_loading / create_moe_runner / apply for a layer of AWQ-quantised experts."""
+
+    MOE_SLOT_MAX_PAIRS = 8           # (token, expert) pairs served one grid row each; beyond: expert-sorted 16-row blocks
+    MOE_GEMV_MAX_SLOTS = MOE_SLOT_MAX_PAIRS   # (name of rounds 1-2)
 
     def __init__(self, quant_config: AWQConfig):
         if quant_config.weight_bits != 4:
             raise ValueError("AWQMoEMethod only supports 4bit now.")        # awq.py:665-666
         self.quant_config = quant_config
+        self.moe_runner_config = None
+
+    def create_moe_runner(self, layer: torch.nn.Module, moe_runner_config) -> None:
+        """awq.py:815-820.  The config is read by attribute (MoeRunnerConfig, layers/moe/moe_runner/base.py:26-46); what this
+        method cannot honour raises here rather than computing something else."""
+        act = getattr(moe_runner_config, "activation", "silu")
+        if act != "silu" or not getattr(moe_runner_config, "is_gated", True):
+            raise NotImplementedError(f"AWQMoEMethod: gated SiLU experts only (activation={act!r})")
+        if getattr(moe_runner_config, "apply_router_weight_on_input", False):
+            raise NotImplementedError("AWQMoEMethod: apply_router_weight_on_input is not supported")
+        if getattr(moe_runner_config, "no_combine", False):
+            raise NotImplementedError("AWQMoEMethod: no_combine is not supported")
+        self.moe_runner_config = moe_runner_config
 
     def create_weights(self, layer: torch.nn.Module, num_experts: int, hidden_size: int, intermediate_size_per_partition: int,
                        params_dtype: torch.dtype, **extra_weight_attrs):
@@ -89,11 +122,11 @@ class AWQMoEMethod:
             layer.w13_packed[e].copy_(ops.awq_repack(*il))
             layer.w2_packed[e].copy_(ops.awq_repack(layer.w2_qweight[e].contiguous(), layer.w2_scales[e].contiguous(), layer.w2_qzeros[e].contiguous()))
 
-    def _moe_gemv(self, x, packed, expert_ids, slot_scale, slots, x_div, K, N, silu):
+    def _moe_gemv(self, x, packed, expert_ids, slot_scale, slots, x_div, K, N, silu, num_experts):
         g = self.quant_config.group_size
         y = torch.empty((slots, N // 2 if silu else N), dtype=torch.float16, device=x.device)
         rc = _lib.load().awq_aux_moe_gemv(ctypes.c_void_p(x.data_ptr()), x.stride(0), int(x_div), ctypes.c_void_p(packed.data_ptr()),
-                                          packed.stride(0), ctypes.c_void_p(expert_ids.data_ptr()),
+                                          packed.stride(0), int(num_experts), ctypes.c_void_p(expert_ids.data_ptr()),
                                           ctypes.c_void_p(slot_scale.data_ptr()) if slot_scale is not None else None,
                                           ctypes.c_void_p(y.data_ptr()), slots, K, N, g, _lib.DTYPE_F16, 1 if silu else 0,
                                           ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
@@ -102,55 +135,92 @@ class AWQMoEMethod:
         _lib.check(rc, "awq_aux_moe_gemv")
         return y
 
-    def apply(self, layer: torch.nn.Module, x: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor) -> torch.Tensor:
-        """x [T, K] fp16, topk_weights [T, top_k] fp32, topk_ids [T, top_k] int32 -> [T, K]."""
-        from . import aux_ops, ops
-
-        E, K, I = layer.num_experts, layer.hidden_size, layer.intermediate_size_per_partition
+    def _moe_blocks(self, x, packed, row_map, block_expert, slot_scale, pairs, x_div, K, N, silu):
         g = self.quant_config.group_size
+        # rows of padded / dropped pairs are never written by the kernel: start from zeros so the top_k sum ignores them
+        y = torch.zeros((pairs, N // 2 if silu else N), dtype=torch.float16, device=x.device)
+        rc = _lib.load().awq_aux_moe_gemv_blocks(ctypes.c_void_p(x.data_ptr()), x.stride(0), int(x_div), ctypes.c_void_p(packed.data_ptr()),
+                                                 packed.stride(0), ctypes.c_void_p(row_map.data_ptr()),
+                                                 ctypes.c_void_p(block_expert.data_ptr()), block_expert.numel(),
+                                                 ctypes.c_void_p(slot_scale.data_ptr()) if slot_scale is not None else None,
+                                                 ctypes.c_void_p(y.data_ptr()), K, N, g, _lib.DTYPE_F16, 1 if silu else 0,
+                                                 ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        if rc == _lib.ERR_BAD_VARIANT:
+            return None
+        _lib.check(rc, "awq_aux_moe_gemv_blocks")
+        return y
+
+    @staticmethod
+    def align_blocks(ids: torch.Tensor, num_experts: int, block: int = 16):
+        """Device-side counterpart of the reference's moe_align_block_size (layers/moe/fused_moe_triton/moe_align_block_size.py):
+        ids [P] int32 -> (row_map [B * block] int32: pair indices sorted by expert, each expert's run padded with -1 to a multiple
+        of `block`; block_expert [B] int32: expert of each block, -1 for unused blocks).  B = ceil(P / block) + num_experts is a
+        static bound, so nothing here depends on the data on the host: no synchronisation, capturable.  Ids outside
+        [0, num_experts) (padded tokens carry -1) are dropped."""
+        P = ids.numel()
+        dev = ids.device
+        E = num_experts
+        B = (P + block - 1) // block + E
+        valid = (ids >= 0) & (ids < E)
+        key = torch.where(valid, ids, torch.full_like(ids, E)).to(torch.int64)          # dropped pairs sort behind every expert
+        order = torch.argsort(key, stable=True)                                          # pair indices, grouped by expert
+        sorted_key = key[order]
+        counts = torch.zeros(E + 1, dtype=torch.int64, device=dev).scatter_add_(0, key, torch.ones_like(key))
+        padded = (counts[:E] + (block - 1)) // block * block
+        starts = torch.cumsum(padded, 0) - padded                                        # first row of each expert in row_map
+        first = torch.cumsum(counts, 0) - counts                                         # first position of each key in `order`
+        rank = torch.arange(P, device=dev, dtype=torch.int64) - first[sorted_key]        # rank of a pair inside its expert's run
+        dest = torch.where(sorted_key < E, starts[sorted_key.clamp(max=E - 1)] + rank, torch.full_like(rank, B * block))
+        row_map = torch.full((B * block + 1,), -1, dtype=torch.int32, device=dev)
+        row_map.scatter_(0, dest, order.to(torch.int32))                                 # dropped pairs land in the spare last slot
+        row_map = row_map[:B * block].contiguous()
+        blk_start = torch.arange(B, device=dev, dtype=torch.int64) * block
+        ends = starts + padded
+        e_of = torch.searchsorted(ends, blk_start, right=True)                           # expert whose padded run holds the block
+        block_expert = torch.where(blk_start < ends[-1], e_of, torch.full_like(e_of, -1)).to(torch.int32)
+        return row_map, block_expert
+
+    def apply(self, layer: torch.nn.Module, dispatch_output, topk_weights: Optional[torch.Tensor] = None,
+              topk_ids: Optional[torch.Tensor] = None):
+        """The reference's call: apply(layer, dispatch_output) -> CombineInput (awq.py:822-845).  For direct use the tensors may be
+        given instead: apply(layer, x, topk_weights, topk_ids) -> Tensor."""
+        if isinstance(dispatch_output, torch.Tensor):
+            return self.apply_tensors(layer, dispatch_output, topk_weights, topk_ids)
+        x = dispatch_output.hidden_states
+        topk = dispatch_output.topk_output
+        out = self.apply_tensors(layer, x, topk.topk_weights, topk.topk_ids)
+        cfg = self.moe_runner_config
+        rsf = getattr(cfg, "routed_scaling_factor", None) if cfg is not None else None
+        if rsf is not None and rsf != 1.0:
+            out = out * rsf                                   # fused_experts_impl multiplies the combined output (moe_sum_reduce)
+        if cfg is not None and getattr(cfg, "inplace", False) and out.shape == x.shape and out.dtype == x.dtype:
+            x.copy_(out)
+            out = x
+        return StandardCombineInput(hidden_states=out)
+
+    def apply_tensors(self, layer: torch.nn.Module, x: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor) -> torch.Tensor:
+        """x [T, K] fp16, topk_weights [T, top_k] fp32, topk_ids [T, top_k] int (ids outside [0, E) = padded) -> [T, K]."""
+        E, K, I = layer.num_experts, layer.hidden_size, layer.intermediate_size_per_partition
         if x.dim() != 2 or x.shape[1] != K or x.dtype != torch.float16:
             raise RuntimeError(f"AWQMoEMethod.apply: x must be fp16 [tokens, {K}]")
         T, top_k = topk_ids.shape
+        if T == 0:
+            return x.new_empty((0, K))
         x = x.contiguous()
         ids = topk_ids.to(torch.int32).contiguous().view(-1)
         wts = topk_weights.to(torch.float32).contiguous().view(-1)
-        slots = T * top_k
-        if 0 < slots <= self.MOE_GEMV_MAX_SLOTS:
-            act = self._moe_gemv(x, layer.w13_packed, ids, None, slots, top_k, K, 2 * I, True)
+        pairs = T * top_k
+        y = None
+        if pairs <= self.MOE_SLOT_MAX_PAIRS:
+            act = self._moe_gemv(x, layer.w13_packed, ids, None, pairs, top_k, K, 2 * I, True, E)
             if act is not None:
-                y = self._moe_gemv(act, layer.w2_packed, ids, wts, slots, 1, I, K, False)
-                if y is not None:
-                    return y.view(T, top_k, K).sum(dim=1, dtype=torch.float32).to(torch.float16)
-        # grouped by expert (host-side grouping: one synchronisation; prefill-sized batches)
-        out = torch.zeros((T, K), dtype=torch.float32, device=x.device)
-        order = torch.argsort(ids, stable=True)
-        counts = torch.bincount(ids, minlength=E).tolist()
-        tok = (order // top_k)
-        start = 0
-        for e, n in enumerate(counts):
-            if n == 0:
-                continue
-            sel = order[start:start + n]
-            rows = tok[start:start + n]
-            xe = x.index_select(0, rows)
-            r = aux_ops.gemv_repacked_fused(layer.w13_packed[e], K, 2 * I, g, x=xe, silu_mul=True) if n <= 32 else None
-            if r is not None:
-                act = r[0]
-            else:
-                gu = ops.awq_gemm_repacked(xe, self._plain_w13(layer, e), K, 2 * I, g)
-                act = aux_ops.silu_mul(gu)
-            ye = ops.awq_gemm_repacked(act, layer.w2_packed[e], I, K, g)
-            # (the dense kernels round each pair's sum to fp16 before the routed weight is applied, the decode route after: the
-            # two routes can differ by an fp16 ulp of a pair's contribution)
-            out.index_add_(0, rows, ye.float() * wts.index_select(0, sel).unsqueeze(1))
-            start += n
-        return out.to(torch.float16)
-
-    def _plain_w13(self, layer, e):
-        """Repacked copy of expert e's w13 in natural (gate | up) column order, made on first use (large batches only)."""
-        from . import ops
-
-        cache = layer.__dict__.setdefault("_w13_plain_packed", {})
-        if e not in cache:
-            cache[e] = ops.awq_repack(layer.w13_qweight[e].contiguous(), layer.w13_scales[e].contiguous(), layer.w13_qzeros[e].contiguous())
-        return cache[e]
+                y = self._moe_gemv(act, layer.w2_packed, ids, wts, pairs, 1, I, K, False, E)
+        if y is None:
+            row_map, block_expert = self.align_blocks(ids, E)
+            act = self._moe_blocks(x, layer.w13_packed, row_map, block_expert, None, pairs, top_k, K, 2 * I, True)
+            if act is None:
+                raise NotImplementedError(f"AWQMoEMethod: no kernel for experts K={K} I={I} group_size={self.quant_config.group_size}")
+            y = self._moe_blocks(act, layer.w2_packed, row_map, block_expert, wts, pairs, 1, I, K, False)
+            if y is None:
+                raise NotImplementedError(f"AWQMoEMethod: no kernel for experts K={K} I={I} group_size={self.quant_config.group_size}")
+        return y.view(T, top_k, K).sum(dim=1, dtype=torch.float32).to(torch.float16)

@@ -85,33 +85,72 @@ def _workspace(dev: torch.device, stream: int) -> torch.Tensor:
     """Scratch per (device, stream): the split-K arrival counters at its head, the fp32 slabs and (M >= 33) the target of
     the on-the-fly re-layout are live for the duration of one call, and calls on one stream are ordered — two streams of
     one device must never share them (alternate-stream overlap, capture on one stream while another runs).  Only the
-    counters need to start at zero; every call leaves them zero again, so a buffer is initialised once, outside any timed or
-    captured region when the first call on that stream is a warm-up (as it is in the reference's graph-capture flow)."""
+    counters need to start at zero; every call leaves them zero again, so a buffer is initialised once.  Never during stream
+    capture: the allocation would come from the graph's private pool and the zero-fill would become a graph node that has
+    not run — a first call on a capturing stream raises; warm the op up on the capture stream first (as the reference's
+    graph runner does, cuda_graph_runner.py:716-719) or call `prepare_stream_workspaces()`."""
     key = (dev.index, stream)
     ws = _workspaces.get(key)
     if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("sglang_awq_amd: the AWQ op needs its per-stream scratch, and the first call on this stream is inside "
+                               "a graph capture. Run the op once eagerly on the capture stream (warm-up), or call "
+                               "sglang_awq_amd.ops.prepare_stream_workspaces(stream) before capturing.")
         ws = torch.empty(_WORKSPACE_BYTES, dtype=torch.uint8, device=dev)
         ws[:4096].zero_()
         _workspaces[key] = ws
     return ws
 
 
+def prepare_stream_workspaces(stream: Optional["torch.cuda.Stream"] = None, device: Optional[torch.device] = None) -> None:
+    """Create (eagerly, on the current stream) the scratch buffers that calls on `stream` will use, so that a capture on that
+    stream never has to allocate: the op's split-K workspace and the decode harness' attention scratch."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    s = torch.cuda.current_stream(dev) if stream is None else stream
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("prepare_stream_workspaces must run outside graph capture")
+    key = (dev.index, s.cuda_stream)
+    if key not in _workspaces:
+        ws = torch.empty(_WORKSPACE_BYTES, dtype=torch.uint8, device=dev)
+        ws[:4096].zero_()
+        _workspaces[key] = ws
+    from . import aux_ops
+
+    aux_ops.prepare_attention_workspace(dev, s.cuda_stream)
+    torch.cuda.current_stream(dev).synchronize()          # the zero-fills are done before any other stream may use the buffers
+
+
 # --------------------------------------------------------------------------- repacked copies kept by the drop-in op
 # `sgl_kernel.awq_gemm` receives the checkpoint tensors on every call; the kernels that reach the HBM roofline want the
-# MFMA-fragment-major layout (awq_repack).  Serving weights are static, so the op keeps one repacked copy per weight it has
-# seen, keyed on the three tensors' storage addresses and validated on every hit by (a) the tensors' version counters
-# (in-place updates such as an RL weight sync bump `_version` -> the copy is rebuilt) and (b) weak references to the
-# storages (a freed weight whose address is reused can never alias a stale copy).  The copy is made on the first eager call
-# for a weight — never during stream capture (a capture-time miss runs the checkpoint-layout kernel) — costs
-# awq_repacked_bytes() of HBM per weight, and can be dropped with awq_gemm_cache_clear() or disabled with
-# SGLANG_AWQ_AMD_OP_CACHE=0.  Results are bit-identical to awq_gemm_repacked (same kernels).
-# Limit of (a): a write through `param.data` (e.g. `param.data.copy_(w)`, which the reference's weight loaders use) bumps the
-# version counter of the temporary `.data` alias, not of the tensor the op receives — after reloading weights in place that
-# way, call awq_gemm_cache_clear() (this package's AWQLinearMethod.process_weights_after_loading does).
+# MFMA-fragment-major layout (awq_repack).  Serving weights are static, so the op can keep one repacked copy per weight it has
+# seen, keyed on the three tensors' storage addresses and validated on every hit by (a) the tensors' version counters and
+# (b) weak references to the storages (a freed weight whose address is reused can never alias a stale copy).
+# (a) has a hole that no check at call time can close: the reference's weight loaders and its hot-update paths write through
+# `param.data.copy_(w)` (layers/parameter.py:59,124), which bumps the version counter of the temporary `.data` alias, not of
+# the tensor the op receives.  The cache is therefore only ON when something guarantees an invalidation after such writes:
+#   * SGLANG_AWQ_AMD_OP_CACHE unset ("auto", the default): off until `sgl_kernel_compat.install()` has hooked the
+#     reference's reload paths (ModelRunner.update_weights_from_* and load_weights_and_postprocess call
+#     `weight_update.weights_updated`, which clears this cache and re-lays this package's layers out), or until the caller
+#     takes responsibility with `awq_gemm_cache_enable(True)`;
+#   * SGLANG_AWQ_AMD_OP_CACHE=1: on from the start (the caller calls awq_gemm_cache_clear() after in-place weight writes);
+#   * SGLANG_AWQ_AMD_OP_CACHE=0: always off.
+# The copy is made on the first eager call for a weight — never during stream capture (a capture-time miss runs the
+# checkpoint-layout kernel, whose fp32 summation order differs: same tolerance, not bit-identical to the cached route) —
+# costs awq_repacked_bytes() of HBM per weight (cap SGLANG_AWQ_AMD_OP_CACHE_GB, default 64), and is dropped by
+# awq_gemm_cache_clear().  Results on a hit are bit-identical to awq_gemm_repacked (same kernels).  Tensors without a version
+# counter (created under torch.inference_mode()) bypass the cache.
 _op_cache = {}
-_OP_CACHE_ENABLED = os.environ.get("SGLANG_AWQ_AMD_OP_CACHE", "1") != "0"
+_OP_CACHE_MODE = {"1": "on", "0": "off"}.get(os.environ.get("SGLANG_AWQ_AMD_OP_CACHE", ""), "auto")
+_OP_CACHE_ENABLED = _OP_CACHE_MODE == "on"
 _OP_CACHE_MAX_BYTES = int(float(os.environ.get("SGLANG_AWQ_AMD_OP_CACHE_GB", "64")) * (1 << 30))
 _op_cache_bytes = 0
+
+
+def _reload_hooks_installed() -> None:
+    """Called by sgl_kernel_compat.install() once the reference's weight-reload paths invalidate the cache ("auto" mode)."""
+    global _OP_CACHE_ENABLED
+    if _OP_CACHE_MODE == "auto":
+        _OP_CACHE_ENABLED = True
 
 
 def awq_gemm_cache_clear() -> None:
@@ -130,7 +169,7 @@ def awq_gemm_cache_enable(flag: bool) -> None:
 
 
 def awq_gemm_cache_info() -> dict:
-    return {"entries": len(_op_cache), "bytes": _op_cache_bytes, "enabled": _OP_CACHE_ENABLED}
+    return {"entries": len(_op_cache), "bytes": _op_cache_bytes, "enabled": _OP_CACHE_ENABLED, "mode": _OP_CACHE_MODE}
 
 
 def _op_cached_repack(qweight, scales, qzeros, K, N, g):
@@ -140,7 +179,10 @@ def _op_cached_repack(qweight, scales, qzeros, K, N, g):
         return None
     key = (qweight.device.index, qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(), K, N, g)
     ent = _op_cache.get(key)
-    versions = (qweight._version, scales._version, qzeros._version)
+    try:
+        versions = (qweight._version, scales._version, qzeros._version)
+    except RuntimeError:                                  # inference tensors track no version counter: nothing to validate against
+        return None
     if ent is not None:
         packed, vers, refs = ent
         if vers == versions and not any(r.expired() for r in refs):
@@ -175,7 +217,7 @@ def _awq_dequantize_hip(qweight: torch.Tensor, scales: torch.Tensor, qzeros: tor
     return out
 
 
-def _gemm_impl(input, qweight, scales, qzeros, bias, split_k_iters, variant=_lib.GEMM_AUTO, tune=0):
+def _gemm_impl(input, qweight, scales, qzeros, bias, split_k_iters, variant=_lib.GEMM_AUTO, tune=0, use_cache=True):
     K, N, g = _check_awq_tensors(qweight, scales, qzeros)
     if input.dim() != 2 or input.shape[1] != K:
         raise RuntimeError(f"awq_gemm: input must be [M, {K}], got {tuple(input.shape)}")
@@ -196,7 +238,7 @@ def _gemm_impl(input, qweight, scales, qzeros, bias, split_k_iters, variant=_lib
     lib = _lib.load()
     dev = input.device
     with _on_device(dev):
-        if variant == _lib.GEMM_AUTO and M > 0 and ldx % 8 == 0 and input.data_ptr() % 16 == 0:
+        if use_cache and variant == _lib.GEMM_AUTO and M > 0 and ldx % 8 == 0 and input.data_ptr() % 16 == 0:
             packed = _op_cached_repack(qweight, scales, qzeros, K, N, g)
             if packed is not None:
                 try:
@@ -225,7 +267,9 @@ def _awq_gemm_hip(input, qweight, scales, qzeros, split_k_iters: int) -> torch.T
 
 
 def _awq_linear_hip(input, qweight, scales, qzeros, bias) -> torch.Tensor:
-    return _gemm_impl(input, qweight, scales, qzeros, bias, 1)
+    # this package's own op: its caller (AWQLinearMethod) either holds a repacked copy already or asked for none
+    # (repack=False, or the fallback after a BAD_VARIANT on the repacked route) — never a second, hidden copy
+    return _gemm_impl(input, qweight, scales, qzeros, bias, 1, use_cache=False)
 
 
 # --------------------------------------------------------------------------- fake (meta) implementations

@@ -26,6 +26,9 @@ def ops():
     from sglang_awq_amd import ops as _ops   # raises if the HIP library is missing: no fallback
 
     _lib.load()
+    # the op's repacked-copy cache is opt-in (ops.py: off until the reload hooks of sgl_kernel_compat.install() are in place or
+    # the caller takes responsibility for invalidation): these tests own their weights and clear the cache themselves
+    _ops.awq_gemm_cache_enable(True)
     return _ops
 
 

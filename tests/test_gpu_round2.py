@@ -18,6 +18,9 @@ def ops():
     from sglang_awq_amd import ops as _ops   # raises if the HIP library is missing: no fallback
 
     _lib.load()
+    # the op's repacked-copy cache is opt-in (ops.py: off until the reload hooks of sgl_kernel_compat.install() are in place or
+    # the caller takes responsibility for invalidation): these tests own their weights and clear the cache themselves
+    _ops.awq_gemm_cache_enable(True)
     return _ops
 
 
@@ -94,7 +97,8 @@ def test_op_cache_invalidation_and_capture(ops):
     assert_gemm_close(to_np(y3), e1, "f16", what=f"cached op after free + realloc (addresses reused: {reused})")
     # explicit clear
     ops.awq_gemm_cache_clear()
-    assert ops.awq_gemm_cache_info() == {"entries": 0, "bytes": 0, "enabled": True}
+    info = ops.awq_gemm_cache_info()
+    assert (info["entries"], info["bytes"], info["enabled"]) == (0, 0, True)
     # capture-time miss: not cached, still right
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -318,7 +322,7 @@ def test_repacked_small_group_one_hot_rows_reproduce_dequantize(ops):
         assert torch.equal(ops.awq_gemm_repacked(xb, packed, K, N, g), W[idx]), dt + " tiled"
 
 
-@pytest.mark.parametrize("T", [1, 3, 8, 40])
+@pytest.mark.parametrize("T", [1, 3, 8, 40, 300])
 def test_awq_moe_method_vs_oracle(ops, T):
     """AWQMoEMethod (reference awq.py:661-852): experts on the fragment-major layout, decode batches through the
     expert-indirect GEMV (awq_aux_moe_gemv: SiLU-mul epilogue, routed weight on the fp32 sums), larger ones grouped by expert.
@@ -368,22 +372,22 @@ def test_awq_moe_method_vs_oracle(ops, T):
     tol = 2.5 * (2.0 ** (np.floor(np.log2(np.maximum(scale, 2.0 ** -14))) - 10)) + 2e-3 * (1.0 + scale)
     err = np.abs(out - want)
     assert np.all(err <= tol), f"T={T}: worst {err.max():.3e} at scale {scale.flat[err.argmax()]:.3f}"
-    # the grouped route (T = 40) rounds a pair's sum before applying the routed weight: more one-ulp differences, same bound
-    assert float((out != want).mean()) < (0.25 if T * top_k <= AWQMoEMethod.MOE_GEMV_MAX_SLOTS else 0.45)
-    if T * top_k <= AWQMoEMethod.MOE_GEMV_MAX_SLOTS:
-        # the decode route holds no host synchronisation: it must capture into a graph and replay to the same bits
-        xt = to_torch(x, DEV)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            eager = method.apply(layer, xt, tw, ti)
-        torch.cuda.current_stream().wait_stream(side)
-        gph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gph, stream=side):
-            captured = method.apply(layer, xt, tw, ti)
-        gph.replay()
-        torch.cuda.synchronize()
-        assert torch.equal(captured, eager)
+    # every route applies the routed weight to the fp32 sums before the one rounding (slot route up to MOE_SLOT_MAX_PAIRS pairs,
+    # expert-sorted 16-row blocks beyond): the same share of one-ulp differences on both
+    assert float((out != want).mean()) < 0.25
+    # no route holds a host synchronisation: each must capture into a graph and replay to the same bits
+    xt = to_torch(x, DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        eager = method.apply(layer, xt, tw, ti)
+    torch.cuda.current_stream().wait_stream(side)
+    gph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gph, stream=side):
+        captured = method.apply(layer, xt, tw, ti)
+    gph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(captured, eager)
 
 
 _KNOB_SNIPPET = r"""

@@ -1,0 +1,380 @@
+"""Round-3 parity additions (-m gpu): the loop form of the decode GEMV (gemv_rp3_kernel) against the oracle and bit for bit
+against the kernels it replaces, the next-weights hint (results must not depend on it), AWQ-MoE behind the reference's call
+interface with padded ids, weight updates through `param.data.copy_` followed by the hook, scratch buffers under graph capture,
+bias loading through apply, outlier activations through the norm-folded GEMV."""
+import ctypes
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import awq_ref, c_oracle
+from sglang_awq_amd import _lib, synth
+from tests.util import assert_gemm_close, to_np, to_torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sglang_awq_amd import ops as _ops   # raises if the HIP library is missing: no fallback
+
+    _lib.load()
+    return _ops
+
+
+def _dev(*arrs):
+    return [to_torch(a, DEV) for a in arrs]
+
+
+# (K, N): deep K on one column group per workgroup (7B down_proj), deep K on wide strips, ragged k-blocks per wave (KB = 86 -> 6 per
+# wave, 4 left for the last wave; KB = 40 -> 3 per wave, waves 14 / 15 empty), wide strips (G = 7: 8192 x 28672 in miniature is too
+# big for the oracle — 2048 x 28672 has the same strip width and 1 k-block per wave is straight-line, so 4096 x 27648 with G = 7)
+LOOP_SHAPES = [(11008, 4096), (5120, 2048), (8192, 1280), (4096, 27648), (2048, 512)]
+
+
+@pytest.mark.parametrize("K,N", LOOP_SHAPES)
+def test_loop_form_gemv_vs_oracle(ops, K, N):
+    """awq_gemm_repacked at every row count of the decode range on shapes the straight-line kernel cannot hold: within half an
+    output ulp + 1e-3 of the exact sum (north star: 1e-3 fp16 atol), bias epilogue = y + bias with a second rounding."""
+    qw, s, qz = synth.make_awq_weights(K, N, 128, "f16", "A", seed=K + N)
+    dq, ds, dz = _dev(qw, s, qz)
+    packed = ops.awq_repack(dq, ds, dz)
+    for M in (1, 2, 3, 6, 8, 9, 12, 16):
+        x = synth.make_activations(M, K, "f16", "A", seed=M + K)
+        _, exact = c_oracle.gemm(x, qw, s, qz, want_exact=True)
+        y = ops.awq_gemm_repacked(to_torch(x, DEV), packed, K, N, 128)
+        assert_gemm_close(to_np(y), exact, "f16", what=f"loop form M={M} K={K} N={N}")
+        if M in (1, 9):
+            b = to_torch(synth.make_bias(N, "f16", 5), DEV)
+            assert torch.equal(ops.awq_gemm_repacked(to_torch(x, DEV), packed, K, N, 128, b), y + b)
+
+
+_AB_SNIPPET = r"""
+import sys, torch
+sys.path.insert(0, {root!r})
+from sglang_awq_amd import ops, synth
+from tests.util import to_torch
+out = {{}}
+for (K, N) in [(11008, 4096), (5120, 2048), (4096, 27648)]:
+    qw, s, qz = synth.make_awq_weights(K, N, 128, "f16", "A", seed=K + N)
+    packed = ops.awq_repack(*[to_torch(t, "cuda:0") for t in (qw, s, qz)])
+    for M in (1, 6, 9, 16):
+        x = to_torch(synth.make_activations(M, K, "f16", "A", seed=M + K), "cuda:0")
+        out[(K, N, M)] = ops.awq_gemm_repacked(x, packed, K, N, 128).cpu()
+torch.save(out, {path!r})
+"""
+
+
+def test_loop_form_is_bit_identical_to_the_kernel_it_replaces(tmp_path):
+    """Same k-block ownership per wave and the same wave-order sum as gemv_repacked_kernel: AWQ_RP3=0 (the round-1 loop kernel,
+    read once per process -> child processes) and the default must agree bit for bit."""
+    res = {}
+    for flag in ("0", "1"):
+        path = str(tmp_path / f"rp3_{flag}.pt")
+        env = dict(os.environ, AWQ_RP3=flag)
+        r = subprocess.run([sys.executable, "-c", _AB_SNIPPET.format(root=ROOT, path=path)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[flag] = torch.load(path, weights_only=True)
+    assert res["0"].keys() == res["1"].keys()
+    for k in res["0"]:
+        assert torch.equal(res["0"][k], res["1"][k]), f"loop form differs from the kernel it replaces at (K, N, M) = {k}"
+
+
+def test_next_weights_hint_changes_nothing(ops):
+    """awq_gemm_repacked_next: the hint only touches (reads and discards) bytes of another buffer; y is bit-identical with and
+    without it, for every wave_min, whatever the hinted shape."""
+    lib = _lib.load()
+    K, N = 4096, 11008
+    w = [synth.make_awq_weights(K, N, 128, "f16", "A", seed=s) for s in (1, 2)]
+    packed = [ops.awq_repack(*_dev(*t)) for t in w]
+    for M in (1, 4, 16):
+        x = to_torch(synth.make_activations(M, K, "f16", "A", seed=M), DEV)
+        y0 = ops.awq_gemm_repacked(x, packed[0], K, N, 128)
+        for budget, wmin in ((1 << 20, 0), (6 << 20, 8), (64 << 20, 12)):
+            hint = _lib.NextHint()
+            rc = lib.awq_next_hint_for_gemm_repacked(ctypes.c_void_p(packed[1].data_ptr()), 1, K, N, 128, _lib.DTYPE_F16, budget, ctypes.byref(hint))
+            assert rc == 0 and hint.ptr == packed[1].data_ptr() and hint.span % 64 == 0
+            assert hint.stride * (hint.regions - 1) + hint.span <= packed[1].numel()          # inside the buffer
+            hint.wave_min = wmin
+            y = torch.empty_like(y0)
+            rc = lib.awq_gemm_repacked_next(ctypes.c_void_p(x.data_ptr()), K, ctypes.c_void_p(packed[0].data_ptr()), None,
+                                            ctypes.c_void_p(y.data_ptr()), None, 0, M, K, N, 128, _lib.DTYPE_F16, ctypes.byref(hint),
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0
+            assert torch.equal(y, y0), f"hint changed the result (M={M}, budget={budget}, wave_min={wmin})"
+    hint = _lib.NextHint()
+    assert lib.awq_next_hint_for_gemm_repacked(ctypes.c_void_p(packed[1].data_ptr()), 1, K, N, 64, _lib.DTYPE_F16, 1 << 20, ctypes.byref(hint)) == _lib.ERR_BAD_VARIANT
+    assert hint.ptr is None
+
+
+def _moe_layer(E, K, I, g, seed0=100):
+    from sglang_awq_amd.awq import AWQConfig
+    from sglang_awq_amd.moe import AWQMoEMethod
+
+    method = AWQMoEMethod(AWQConfig(4, g, True))
+    layer = torch.nn.Module()
+    method.create_weights(layer, E, K, I, torch.float16)
+    w13 = [synth.make_awq_weights(K, 2 * I, g, "f16", "A", seed=seed0 + e) for e in range(E)]
+    w2 = [synth.make_awq_weights(I, K, g, "f16", "A", seed=seed0 + 100 + e) for e in range(E)]
+    for e in range(E):
+        layer.w13_qweight.data[e].copy_(to_torch(w13[e][0])); layer.w13_scales.data[e].copy_(to_torch(w13[e][1])); layer.w13_qzeros.data[e].copy_(to_torch(w13[e][2]))
+        layer.w2_qweight.data[e].copy_(to_torch(w2[e][0])); layer.w2_scales.data[e].copy_(to_torch(w2[e][1])); layer.w2_qzeros.data[e].copy_(to_torch(w2[e][2]))
+    layer.to(DEV)
+    method.process_weights_after_loading(layer)
+    return method, layer
+
+
+@pytest.mark.parametrize("T", [2, 24])
+def test_moe_reference_interface_and_padded_ids(ops, T):
+    """create_moe_runner + apply(layer, dispatch_output) -> CombineInput (reference awq.py:815-845) with duck-typed
+    StandardDispatchOutput / StandardTopKOutput / MoeRunnerConfig; ids of -1 (the reference's padded tokens of a graph batch,
+    layers/moe/topk.py:705-712) and ids >= E contribute zero on both routes — an all-padded token gives an exactly zero row —
+    and the tensor form gives the same bits."""
+    from sglang_awq_amd.moe import StandardCombineInput, select_experts
+
+    E, K, I, top_k, g = 4, 2048, 512, 2, 128
+    method, layer = _moe_layer(E, K, I, g, seed0=300)
+    method.create_moe_runner(layer, types.SimpleNamespace(activation="silu", is_gated=True, apply_router_weight_on_input=False,
+                                                          no_combine=False, inplace=False, routed_scaling_factor=None, top_k=top_k,
+                                                          num_experts=E))
+    x = to_torch(synth.make_activations(T, K, "f16", "A", seed=T, x_std=0.5), DEV)
+    tw, ti = select_experts(to_torch(synth.make_activations(T, E, "f16", "A", seed=T + 9).astype(np.float32), DEV), top_k)
+    full = method.apply(layer, x, tw, ti)
+    ti_pad = ti.clone()
+    ti_pad[T - 1, :] = -1                       # a padded token
+    ti_pad[0, 1] = E + 3                        # an out-of-range id
+    disp = types.SimpleNamespace(hidden_states=x, hidden_states_scale=None,
+                                 topk_output=types.SimpleNamespace(topk_weights=tw, topk_ids=ti_pad, router_logits=None))
+    out = method.apply(layer, disp)
+    assert isinstance(out, StandardCombineInput) and out.format == "standard"
+    y = out.hidden_states
+    assert y.shape == (T, K) and torch.isfinite(y).all()
+    assert torch.count_nonzero(y[T - 1]) == 0, "a token whose ids are all -1 must come out as zeros"
+    assert torch.equal(y, method.apply(layer, x, tw, ti_pad))
+    if T > 2:
+        assert torch.equal(y[1:T - 1], full[1:T - 1]), "rows without padded ids must not change"
+    # token 0 keeps only its first expert: its row equals the one-expert computation
+    one = method.apply(layer, x[:1].contiguous(), tw[:1, :1].contiguous(), ti[:1, :1].contiguous())
+    assert torch.equal(y[0], one[0])
+    with pytest.raises(NotImplementedError):
+        method.create_moe_runner(layer, types.SimpleNamespace(activation="gelu", is_gated=True))
+    # routed_scaling_factor is applied to the combined output
+    method.create_moe_runner(layer, types.SimpleNamespace(activation="silu", is_gated=True, routed_scaling_factor=2.0, inplace=False))
+    assert torch.equal(method.apply(layer, disp).hidden_states, y * 2.0)
+
+
+def test_moe_block_route_matches_slot_route(ops):
+    """The expert-sorted 16-row blocks (awq_aux_moe_gemv_blocks, gemv_rp3_kernel with a row map) and the one-row-per-pair launch
+    (awq_aux_moe_gemv) round at the same points: the same pairs through both give bit-identical outputs."""
+    from sglang_awq_amd.moe import AWQMoEMethod, select_experts
+
+    E, K, I, top_k, g = 4, 2048, 512, 2, 128
+    method, layer = _moe_layer(E, K, I, g, seed0=500)
+    T = 4
+    x = to_torch(synth.make_activations(T, K, "f16", "A", seed=3, x_std=0.5), DEV)
+    tw, ti = select_experts(to_torch(synth.make_activations(T, E, "f16", "A", seed=4).astype(np.float32), DEV), top_k)
+    assert T * top_k <= AWQMoEMethod.MOE_SLOT_MAX_PAIRS
+    y_slot = method.apply(layer, x, tw, ti)
+    saved = AWQMoEMethod.MOE_SLOT_MAX_PAIRS
+    try:
+        AWQMoEMethod.MOE_SLOT_MAX_PAIRS = 0
+        y_blk = method.apply(layer, x, tw, ti)
+    finally:
+        AWQMoEMethod.MOE_SLOT_MAX_PAIRS = saved
+    assert torch.equal(y_slot, y_blk)
+
+
+def test_weights_updated_after_data_copy(ops):
+    """The reference reloads weights through `param.data.copy_` (layers/parameter.py:59,124), which no version counter shows.
+    Without the hook both the layer's repacked copy and the op's cached copy keep serving the old weights (asserted: that is the
+    hazard); `weights_updated(model)` — what sgl_kernel_compat.install() makes ModelRunner.update_weights_from_* call —
+    brings both to the new values."""
+    from sglang_awq_amd import weight_update
+    from sglang_awq_amd.awq import AWQConfig, AWQLinearMethod
+
+    K, N = 1024, 2048
+    w1 = synth.make_awq_weights(K, N, 128, "f16", "A", 11)
+    w2 = synth.make_awq_weights(K, N, 128, "f16", "A", 22)
+    x = synth.make_activations(3, K, "f16", "A", 5)
+    xt = to_torch(x, DEV)
+    _, e1 = c_oracle.gemm(x, *w1, want_exact=True)
+    _, e2 = c_oracle.gemm(x, *w2, want_exact=True)
+    method = AWQLinearMethod(AWQConfig(4, 128, True))
+    layer = torch.nn.Module()
+    method.create_weights(layer, K, [N], K, N, torch.float16, weight_loader=None)
+    layer.quant_method = method
+    for name, t in zip(("qweight", "scales", "qzeros"), w1):
+        getattr(layer, name).data.copy_(to_torch(t))
+    model = torch.nn.Sequential(layer).to(DEV)
+    method.process_weights_after_loading(layer)
+    ops.awq_gemm_cache_enable(True)
+    try:
+        assert_gemm_close(to_np(method.apply(layer, xt)), e1, "f16", what="before the update")
+        y_op1 = torch.ops.sgl_kernel.awq_gemm(xt, layer.qweight, layer.scales, layer.qzeros, 1)
+        assert ops.awq_gemm_cache_info()["entries"] == 1
+        for name, t in zip(("qweight", "scales", "qzeros"), w2):
+            getattr(layer, name).data.copy_(to_torch(t, DEV))          # how the reference's weight loaders write
+        # the hazard: nothing noticed
+        assert torch.equal(torch.ops.sgl_kernel.awq_gemm(xt, layer.qweight, layer.scales, layer.qzeros, 1), y_op1)
+        # the hook
+        assert weight_update.weights_updated(model) == 1
+        assert ops.awq_gemm_cache_info()["entries"] == 0
+        assert_gemm_close(to_np(method.apply(layer, xt)), e2, "f16", what="apply after weights_updated")
+        assert_gemm_close(to_np(torch.ops.sgl_kernel.awq_gemm(xt, layer.qweight, layer.scales, layer.qzeros, 1)), e2, "f16",
+                          what="op after weights_updated")
+    finally:
+        ops.awq_gemm_cache_clear()
+
+
+def test_cache_is_opt_in_and_inference_tensors_bypass_it():
+    """A fresh process: the op's cache is off until someone vouches for invalidation (ops._OP_CACHE_MODE "auto");
+    sgl_kernel_compat.install() switches it on together with the reload hooks.  Weights created under torch.inference_mode() have
+    no version counter: the op must still work (cache bypassed), not raise."""
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from sglang_awq_amd import ops, synth, sgl_kernel_compat
+from tests.util import to_torch
+assert ops.awq_gemm_cache_info()["enabled"] is False and ops.awq_gemm_cache_info()["mode"] == "auto"
+K, N = 1024, 1024
+qw, s, qz = [to_torch(t, "cuda:0") for t in synth.make_awq_weights(K, N, 128, "f16", "A", 1)]
+x = to_torch(synth.make_activations(2, K, "f16", "A", 2), "cuda:0")
+y0 = ops.awq_gemm(x, qw, s, qz, 1)
+assert ops.awq_gemm_cache_info()["entries"] == 0
+sgl_kernel_compat.install(force_module=True)
+assert ops.awq_gemm_cache_info()["enabled"] is True
+y1 = ops.awq_gemm(x, qw, s, qz, 1)
+assert ops.awq_gemm_cache_info()["entries"] == 1
+assert (y0.float() - y1.float()).abs().max().item() < 2e-2
+with torch.inference_mode():
+    qi, si, zi = qw.clone(), s.clone(), qz.clone()
+    yi = ops.awq_gemm(x, qi, si, zi, 1)
+assert ops.awq_gemm_cache_info()["entries"] == 1
+assert torch.equal(yi.cpu(), y0.cpu())
+print("OPT_IN_OK")
+""" % ROOT
+    env = {k: v for k, v in os.environ.items() if k != "SGLANG_AWQ_AMD_OP_CACHE"}
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OPT_IN_OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_scratch_is_never_created_during_capture(ops):
+    """A first call on a capturing stream that needs the per-stream scratch raises (allocation would come from the graph's private
+    pool, the zero-fill would be an un-run graph node); after prepare_stream_workspaces(stream) the same capture works and
+    replays to the eager bits — the split-K route at 16 rows on 11008 x 4096."""
+    K, N, M = 11008, 4096, 16
+    qw, s, qz = synth.make_awq_weights(K, N, 128, "f16", "A", 77)
+    packed = ops.awq_repack(*_dev(qw, s, qz))
+    x = to_torch(synth.make_activations(M, K, "f16", "A", 78), DEV)
+    want = ops.awq_gemm_repacked(x, packed, K, N, 128)          # eager, on the current stream
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="scratch"):
+        with torch.cuda.graph(g, stream=side):
+            ops.awq_gemm_repacked(x, packed, K, N, 128)
+    torch.cuda.synchronize()
+    ops.prepare_stream_workspaces(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        y = ops.awq_gemm_repacked(x, packed, K, N, 128)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, want)
+
+
+def test_graphed_decoder_captures_batch16_without_prior_call_on_the_capture_stream(ops):
+    """GraphedDecoder.capture() warms up and captures on one stream: batch 16 at 7B widths (split-K down_proj, split-S attention off)
+    must capture (no eager fallback) and replay to the eager tokens."""
+    from sglang_awq_amd.awq import AWQConfig
+    from sglang_awq_amd.llama import GraphedDecoder, LlamaConfig, LlamaForCausalLM
+
+    cfg = LlamaConfig(hidden_size=4096, intermediate_size=11008, num_hidden_layers=1, num_attention_heads=32, num_key_value_heads=32,
+                      vocab_size=1024)
+    torch.manual_seed(0)
+    model = LlamaForCausalLM(cfg, AWQConfig(4, 128, True), max_batch=16, max_seq=64).to(DEV)
+    model.init_synthetic_(seed=3)
+    dec = GraphedDecoder(model, 16, start_pos=8)
+    dec.tokens.copy_(torch.arange(16, device=DEV) % cfg.vocab_size)
+    ref = GraphedDecoder(model, 16, start_pos=8)
+    ref.tokens.copy_(dec.tokens)
+    dec.capture(warmup=2)
+    assert dec.graph is not None and dec.capture_error is None, dec.capture_error
+    got = dec.run(3)
+    for layer in model.layers:
+        layer.k_cache.zero_(); layer.v_cache.zero_()
+    for _ in range(5):                                     # 2 warm-up steps + 3 timed ones, eagerly
+        ref._step()
+    assert got == ref.tokens.tolist()
+
+
+def test_bias_loaded_and_applied_through_apply(ops):
+    """Bias parameters carry the reference's weight_loader / output_dim = 0 (linear.py:348-358, 1286-1293): a q/k/v bias loads as
+    shards of qkv_proj.bias and is applied by the fused bias epilogue (out = fp16(sum), then out + bias with a second rounding:
+    awq.py:449-450)."""
+    from sglang_awq_amd.awq import AWQConfig
+    from sglang_awq_amd.linear import QKVParallelLinear, RowParallelLinear
+
+    H, hd, nh, nkv = 1024, 128, 8, 2
+    quant = AWQConfig(4, 128, True)
+    qkv = QKVParallelLinear(H, hd, nh, nkv, bias=True, quant_config=quant, params_dtype=torch.float16, tp_rank=0, tp_size=1)
+    N = (nh + 2 * nkv) * hd
+    qw, s, qz = synth.make_awq_weights(H, N, 128, "f16", "A", 41)
+    b = synth.make_bias(N, "f16", 42)
+    sizes = {"q": nh * hd, "k": nkv * hd, "v": nkv * hd}
+    off = 0
+    for sid in ("q", "k", "v"):
+        n = sizes[sid]
+        qkv.qweight.weight_loader(qkv.qweight, to_torch(qw[:, off // 8:(off + n) // 8]), sid)
+        qkv.qzeros.weight_loader(qkv.qzeros, to_torch(qz[:, off // 8:(off + n) // 8]), sid)
+        qkv.scales.weight_loader(qkv.scales, to_torch(s[:, off:off + n]), sid)
+        qkv.bias.weight_loader(qkv.bias, to_torch(b[off:off + n]), sid)
+        off += n
+    qkv.to(DEV)
+    qkv.process_weights_after_loading()
+    assert torch.equal(qkv.bias.cpu(), to_torch(b))
+    for M in (1, 5, 40):
+        x = synth.make_activations(M, H, "f16", "A", M)
+        y, ob = qkv(to_torch(x, DEV))
+        assert ob is None
+        want = awq_ref.awq_linear_apply(x, qw, s, qz, b).astype(np.float64)
+        got = to_np(y).astype(np.float64)
+        ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(want), 2.0 ** -14))) - 10)
+        assert np.all(np.abs(got - want) <= 1.01 * ulp + 1e-3), f"M={M}: {np.abs(got - want).max()}"
+    # row-parallel: replicated bias, loaded whole
+    row = RowParallelLinear(H, 512, bias=True, quant_config=quant, params_dtype=torch.float16, tp_rank=0, tp_size=1)
+    rb = synth.make_bias(512, "f16", 43)
+    row.bias.weight_loader(row.bias, to_torch(rb))
+    assert torch.equal(row.bias, to_torch(rb))
+
+
+def test_norm_folded_gemv_with_outlier_channels(ops):
+    """Massive residual activations (|h| ~ 8000 in a few channels) with a norm weight above 1: the folded form stages
+    x' = fp16((h + delta) * w) un-normalised, which would overflow fp16; the harness must either stay finite and close to the fp32
+    RMSNorm -> linear result, or decline (None) so the caller runs the separate norm."""
+    from sglang_awq_amd import aux_ops
+
+    K, N = 4096, 4096
+    qw, s, qz = synth.make_awq_weights(K, N, 128, "f16", "A", 91)
+    packed = ops.awq_repack(*_dev(qw, s, qz))
+    h = synth.make_activations(2, K, "f16", "A", 92).astype(np.float32)
+    h[:, [7, 1033, 4000]] = [8000.0, -6000.0, 7000.0]
+    w = np.full(K, 1.0, np.float32); w[[7, 1033]] = 12.0            # 8000 * 12 > 65504
+    ht, dt_, wt = to_torch(h.astype(np.float16), DEV), torch.zeros(2, K, dtype=torch.float16, device=DEV), to_torch(w.astype(np.float16), DEV)
+    r = aux_ops.gemv_repacked_fused(packed, K, N, 128, norm=(ht, dt_, wt, 1e-5))
+    hf = torch.from_numpy(h.astype(np.float16).astype(np.float32))
+    xn = (hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + 1e-5)).to(torch.float16) * torch.from_numpy(w.astype(np.float16))
+    _, exact = c_oracle.gemm(xn.numpy(), qw, s, qz, want_exact=True)
+    if r is None:
+        return                                               # declined: the caller runs add_rmsnorm + the plain GEMV
+    y = to_np(r[0]).astype(np.float64)
+    assert np.isfinite(y).all(), "the folded norm overflowed fp16 on outlier channels"
+    scale = np.abs(exact).max()
+    assert np.abs(y - exact).max() <= 2e-2 * scale + 1e-2, f"folded norm with outliers off by {np.abs(y - exact).max()} (scale {scale})"
