@@ -119,10 +119,11 @@ def cpu_baseline(budget_s: float, M: int):
                       f"{el:.1f} s on {torch.get_num_threads()} threads ({os.cpu_count()} logical CPUs)"}
 
 
-def pmc_traffic(kernel_substr: str):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/*pmc_fetch_size*gemv*m1.csv and
-    the matching write_size file; newest round first): 2 x FETCH_SIZE (gfx950 reports half of a wide coalesced read
-    stream, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, both in KiB per dispatch.  None if no committed pass has the kernel."""
+def pmc_traffic(kernel_substr: str, tag: str = "*m1*"):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r*_pmc_fetch_size_<tag>.csv and the
+    matching write_size file; newest round first): 2 x FETCH_SIZE (gfx950 reports half of a wide coalesced read stream,
+    MI355X_MICROARCH.md §HBM) + WRITE_SIZE, both in KiB per dispatch, averaged over the dispatches of the kernel (launches of a
+    multi-launch operator are summed per call by the caller).  (None, []) if no committed pass has the kernel."""
     def mean_counter(path, counter):
         vals = []
         with open(path, newline="") as f:
@@ -131,7 +132,7 @@ def pmc_traffic(kernel_substr: str):
                     vals.append(float(row["Counter_Value"]))
         return sum(vals) / len(vals) if vals else None
 
-    for fetch_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_size_*m1*.csv")), reverse=True):
+    for fetch_path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_fetch_size_{tag}.csv")), reverse=True):
         write_path = fetch_path.replace("fetch_size", "write_size")
         if not os.path.exists(write_path):
             continue
@@ -139,6 +140,13 @@ def pmc_traffic(kernel_substr: str):
         if fk is not None and wk is not None:
             return int((2 * fk + wk) * 1024), [os.path.relpath(fetch_path, ROOT), os.path.relpath(write_path, ROOT)]
     return None, []
+
+
+def pmc_traffic_sum(kernel_substr: str, tag: str, launches_per_call: int):
+    """Traffic of an operator that is several launches of one kernel family per call (the prefill's wide + narrow tile regions):
+    the per-dispatch mean x launches per call."""
+    t, files = pmc_traffic(kernel_substr, tag)
+    return (t * launches_per_call if t is not None else None), files
 
 
 def rccl_summary(log_glob: str):
@@ -362,6 +370,15 @@ def main():
         return e0.elapsed_time(e1) * 1e-3
 
     run_steps(args.warmup)
+    # beyond the W warm-up steps: bring the chip to its steady clocks before the timed region (the first launches after an idle
+    # period run up to 10 % slower; with K = 20 the whole timed region is ~0.3 ms).  Untimed; a fixed ~0.25 s of the same steps.
+    clock_warm = 0
+    if not cpu_rehearsal and world == 1:
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < 0.25:
+            run_steps(max(args.warmup, sets))
+            clock_warm += max(args.warmup, sets)
+            sync()
     wall = timed_wall(args.steps)
     ev = timed_events(args.steps)
     if world > 1:
@@ -389,7 +406,8 @@ def main():
     # cache-hot variant: one weight set only (fits the 256 MiB Infinity Cache)
     hot = None
     if sections and M <= 64:
-        hot = graph_time(lambda: step(0), len(plan), 1000)
+        HOT = 32                       # one graph of 32 steps on weight set 0 (a 2-launch graph would time the replay overhead)
+        hot = graph_time(lambda: [step(0) for _ in range(HOT)], HOT * len(plan), 2000)
 
     # ---- prefill (BASELINE configs[2]): the same layers at M = 2048, MFMA-bound --------------------------------
     prefill = None
@@ -403,6 +421,11 @@ def main():
                    "GBps": round(linear_bytes(MP, K_DIM, N_DIM) / us / 1e3, 1),
                    "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None}}
+        # two launches per call at this shape (wide + narrow tile regions): traffic = sum over both, from the committed PMC passes
+        pt, pfiles = pmc_traffic_sum("gemm_repacked_pipelined_kernel", "prefill*", 2)
+        prefill["roofline"]["traffic"] = pt
+        prefill["roofline"]["traffic_note"] = (f"2 launches x mean (2 x FETCH_SIZE + WRITE_SIZE) per dispatch from {pfiles}; algorithmic bytes "
+                                               f"{linear_bytes(MP, K_DIM, N_DIM)}: every 128-row tile re-reads its weight columns (served by L2 / Infinity Cache)")
         del xp
 
     # ---- awq_dequantize (the op of BASELINE configs[0], on the GPU): HBM-bound, 113,602,560 B per call ---------
@@ -433,13 +456,20 @@ def main():
                    "roofline": {"bound": "hbm", "achieved": round(nbytes / us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBPS, 4), "frac_of_measured_copy": round(nbytes / us / 1e3 / HBM_COPY_GBPS, 4),
                                 "traffic": None}}
+        dtr, dfiles = pmc_traffic("dequant_kernel", "dequant*")
+        dequant["roofline"]["traffic"] = dtr
+        dequant["roofline"]["traffic_note"] = f"2 x FETCH_SIZE + WRITE_SIZE per dispatch from {dfiles} (separate --pmc runs, not collected live)"
         del outs, w_op
 
     # ---- the drop-in op `sgl_kernel.awq_gemm` on the checkpoint tensors, same rotation of weight sets -----------
     op_rec = None
     if "op" in sections:
         cols = [ls[0] for ls in layer_sets]
-        op_rec = {"cache": ops.awq_gemm_cache_info()["enabled"]}
+        # the op's repacked-copy cache is opt-in (off until sgl_kernel_compat.install() has hooked the reference's weight-update
+        # paths, or the caller vouches for invalidation): this benchmark owns its weights and never rewrites them
+        cache_default = ops.awq_gemm_cache_info()
+        ops.awq_gemm_cache_enable(True)
+        op_rec = {"cache": True, "cache_default": f"{cache_default['mode']} (enabled={cache_default['enabled']} before this section switched it on)"}
         for rows in (1, 2048):
             xo = make_x(rows)[0]
 
@@ -459,9 +489,9 @@ def main():
             op_rec[f"m{rows}"] = rec
         op_rec["note"] = ("torch.ops.sgl_kernel.awq_gemm(x, qweight, scales, qzeros, 1) on the AutoAWQ tensors; with the cache on, the op keeps "
                           "one MFMA-fragment-major copy per weight (made on the first eager call, validated by tensor versions and storage "
-                          "weak references) and runs the same kernels as awq_gemm_repacked; SGLANG_AWQ_AMD_OP_CACHE=0 gives the "
-                          "checkpoint-layout split-K kernel (13 us at M = 1)")
-        ops.awq_gemm_cache_clear()
+                          "weak references, dropped by the weight-update hooks of sgl_kernel_compat.install()) and runs the same kernels as "
+                          "awq_gemm_repacked; with the cache off the checkpoint-layout split-K kernel runs (13 us at M = 1)")
+        ops.awq_gemm_cache_enable(False)           # also drops the copies
 
     # context only (not the metric): the same decode kernel on a 70B-class matrix, where the fixed per-launch costs
     # (kernel boundary, time to first load, reduction) amortise — what fraction of peak the kernel itself reaches
@@ -496,7 +526,12 @@ def main():
                                 "1024 positions already in the KV cache; greedy; synthetic weights; whole step replayed from one HIP graph",
                       "weight_GB_per_step": recs[0]["weight_GB_per_step"]}
             for r in recs:
-                decode[f"bs{r['batch']}"] = {k: r[k] for k in ("value", "unit", "median_step_ms", "device_step_ms", "tok_per_s_device", "hbm_GBps_device")}
+                decode[f"bs{r['batch']}"] = {k: r[k] for k in ("value", "unit", "median_step_ms", "device_step_ms", "tok_per_s_device", "hbm_GBps_device",
+                                                               "norm_order", "graph_replay")}
+            if args.cpu_seconds > 0:
+                from sglang_awq_amd.llama import LlamaConfig
+
+                decode["cpu_baseline"] = bench_decode.decode_cpu_baseline(LlamaConfig.llama2_7b(), min(args.cpu_seconds, 8.0))
         except Exception as e:      # the headline must not be lost to the harness
             decode = {"error": repr(e)}
 
@@ -520,7 +555,7 @@ def main():
                                 f"Llama-2-70B TP=8 per-rank AWQ linears at M={M} (BASELINE configs[4]): qkv 8192->1280, o 1024->8192, gate_up 8192->7168, down 3584->8192")
                                + (f" + RCCL all-reduce {ar_payloads} B" if world > 1 else ""),
                    "per_rank_linears": [f"{kind} {K}x{N}" for kind, K, N in rank_shapes],
-                   "weight_sets": sets, "graph_replay": use_graph, "graph_capture_error": capture_error, "parallelism": f"tp{world}",
+                   "weight_sets": sets, "extra_clock_warmup_steps": clock_warm, "graph_replay": use_graph, "graph_capture_error": capture_error, "parallelism": f"tp{world}",
                    "tflops": round(world * flops_step_rank * args.steps / wall / 1e12, 3),
                    "weight_layout": "MFMA-fragment-major copy made once at load (awq_repack); checkpoint tensors kept",
                    "same_kernel_large_matrix": big},

@@ -83,7 +83,8 @@ def measure(model_name: str, batches, steps: int = 64, context: int = 1024, dev=
              "tok_per_s_device": round(B / (dev_ms * 1e-3), 1), "context": context, "steps": steps,
              "weight_GB_per_step": round((lin_bytes + head_bytes) / 1e9, 3),
              "hbm_GBps_device": round((lin_bytes + head_bytes) / (dev_ms * 1e-3) / 1e9, 1), "data": "synthetic", "dtype": "f16",
-             "graph_replay": dec.graph is not None, "graph_capture_error": dec.capture_error}
+             "graph_replay": dec.graph is not None, "graph_capture_error": dec.capture_error,
+             "norm_order": model.layers[0].norm_order(B)}
         results.append(r)
         if verbose:
             print(json.dumps(r), flush=True)
@@ -91,6 +92,35 @@ def measure(model_name: str, batches, steps: int = 64, context: int = 1024, dev=
     del model
     torch.cuda.empty_cache()
     return results
+
+
+def decode_cpu_baseline(cfg, budget_s: float):
+    """The reference's CPU form of a decode step's AWQ linears — eager-torch dequantise + matmul (awq_triton.py:342-368 +
+    awq.py:447, restated in oracle/torch_cpu.py) — timed on ONE decoder layer's four linears at batch 1 and scaled by the layer
+    count (attention, norms and lm_head not counted: an upper bound on the CPU's tok/s).  Bounded by `budget_s` seconds."""
+    import torch
+
+    from oracle import torch_cpu
+    from sglang_awq_amd import synth
+
+    shapes = [(cfg.hidden_size, (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * cfg.head_dim), (cfg.hidden_size, cfg.hidden_size),
+              (cfg.hidden_size, 2 * cfg.intermediate_size), (cfg.intermediate_size, cfg.hidden_size)]
+    tens = []
+    for i, (K, N) in enumerate(shapes):
+        qw, s, qz = synth.make_awq_weights(K, N, 128, "f16", "A", 50 + i)
+        x = synth.make_activations(1, K, "f16", "A", 60 + i)
+        tens.append(tuple(torch.from_numpy(a.copy()) for a in (x, qw, s, qz)))
+    for x, qw, s, qz in tens:
+        torch_cpu.linear_cpu(x, qw, s, qz)
+    n, t0 = 0, time.perf_counter()
+    while n < 1 or time.perf_counter() - t0 < budget_s:
+        for x, qw, s, qz in tens:
+            torch_cpu.linear_cpu(x, qw, s, qz)
+        n += 1
+    per_layer = (time.perf_counter() - t0) / n
+    return {"value": round(1.0 / (per_layer * cfg.num_hidden_layers), 4), "unit": "tok/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} x the four AWQ linears of ONE decoder layer at batch 1 (eager torch CPU dequantise + matmul), "
+                      f"{per_layer * 1e3:.0f} ms per layer, scaled by {cfg.num_hidden_layers} layers; attention / lm_head not counted"}
 
 
 def main():
@@ -118,29 +148,7 @@ def main():
     cfg = {"7b": LlamaConfig.llama2_7b, "70b": LlamaConfig.llama2_70b}.get(args.model, lambda: LlamaConfig(
         hidden_size=512, intermediate_size=1024, num_hidden_layers=4, num_attention_heads=8, num_key_value_heads=8, vocab_size=2048))()
 
-    cpu = None
-    if args.cpu_seconds > 0 and rank == 0:
-        from oracle import torch_cpu
-        from sglang_awq_amd import synth
-
-        shapes = [(cfg.hidden_size, 3 * cfg.hidden_size), (cfg.hidden_size, cfg.hidden_size),
-                  (cfg.hidden_size, 2 * cfg.intermediate_size), (cfg.intermediate_size, cfg.hidden_size)]
-        tens = []
-        for i, (K, N) in enumerate(shapes):
-            qw, s, qz = synth.make_awq_weights(K, N, 128, "f16", "A", 50 + i)
-            x = synth.make_activations(1, K, "f16", "A", 60 + i)
-            tens.append(tuple(torch.from_numpy(a.copy()) for a in (x, qw, s, qz)))
-        for x, qw, s, qz in tens:
-            torch_cpu.linear_cpu(x, qw, s, qz)
-        n, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < args.cpu_seconds:
-            for x, qw, s, qz in tens:
-                torch_cpu.linear_cpu(x, qw, s, qz)
-            n += 1
-        per_layer = (time.perf_counter() - t0) / n
-        cpu = {"value": round(1.0 / (per_layer * cfg.num_hidden_layers), 4), "unit": "tok/s", "cores": torch.get_num_threads(), "kind": "port",
-               "sample": f"{n} x the four AWQ linears of ONE decoder layer at batch 1 (eager torch CPU dequantise + matmul), "
-                         f"{per_layer * 1e3:.0f} ms per layer, scaled by {cfg.num_hidden_layers} layers; attention / lm_head not counted"}
+    cpu = decode_cpu_baseline(cfg, args.cpu_seconds) if (args.cpu_seconds > 0 and rank == 0) else None
     if rank == 0:
         print(json.dumps({"summary": {f"b{r['batch']}": r["value"] for r in results}, "unit": "tok/s", "cpu_baseline": cpu}), flush=True)
 

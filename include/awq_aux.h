@@ -67,7 +67,7 @@ int awq_aux_moe_gemv(const void* x, int64_t ldx, int x_div, const void* packed_e
  * the pairs row_map[16 b .. 16 b + 15] (pair index p -> activation row p / x_div; -1 = padding, nothing is stored for it) with
  * the repacked weight of expert block_expert[b] (< 0: unused block, skipped) and writes output row p of y [pairs, N] (or
  * [pairs, N / 2] with silu_mul); slot_scale[p] as in awq_aux_moe_gemv.  One launch streams each active expert once per 16 of its
- * rows.  fp16, group_size % 128 == 0, K >= 2048; AWQ_ERR_BAD_VARIANT otherwise. */
+ * rows.  fp16, group_size % 128 == 0; AWQ_ERR_BAD_VARIANT otherwise. */
 int awq_aux_moe_gemv_blocks(const void* x, int64_t ldx, int x_div, const void* packed_experts, int64_t expert_stride_bytes,
                             const int32_t* row_map, const int32_t* block_expert, int64_t num_blocks, const float* slot_scale,
                             void* y, int64_t K, int64_t N, int64_t group_size, int dtype, int silu_mul, void* stream);

@@ -250,7 +250,9 @@ int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
   // wave: deep K, wide strips) runs its loop form, gemv_rp3_kernel (awq_repacked_loop.hip): same ring, x / zs staged per stage.
   // AWQ_RP3=0: the round-1 loop kernel instead (A/B)
   static const int env_rp3 = rp_env("AWQ_RP3", 1);
-  if (env_rp3 && !two_tiles && !rounds && KB >= 16 && env_t != 0 && env_waves == 0 && env_g == 0) {
+  // measured (profiles/r03_kbench_rp3_ab.txt): faster than the round-1 loop kernel at 13..16 rows on narrow strips (11008 x 4096 at 16
+  // rows 14.4 -> 13.1 us, 8192 x 1280 10.4 -> 8.5), slower below and on wide strips (register pressure: G >= 4 spills at 16 waves)
+  if (env_rp3 && !two_tiles && !rounds && KB >= 16 && env_t != 0 && env_waves == 0 && env_g == 0 && a.M >= 13 && G <= 2) {
     const int rc = launch_gemv_repacked_loop(a, packed);
     if (rc != AWQ_ERR_BAD_VARIANT) return rc;
   }

@@ -634,6 +634,9 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
 // rp2 exists for T <= 8, G <= 8, G T <= 16 (unrolled length), staging of <= 8 chunks per lane; returns false when the
 // (G, T, chunks) combination has no instantiation (caller falls back to gemv_repacked_kernel)
 constexpr bool rp2_fits(int G, int T) { return G >= 1 && G <= kRpMaxG && T >= 1 && T <= 8 && G * T <= 16; }
+// One row, plain operator: up to 32 units per wave (deep K at 16 waves — 70B down_proj, T = 14 — and wide strips on deep K — the
+// 8192 x 28672 matrix, G = 7, T = 4); straight-line code of G T units, the same ring and staging.
+constexpr bool rp2_fits_long(int G, int T) { return G >= 1 && G <= kRpMaxG && T >= 1 && T <= 16 && G * T <= 32 && !rp2_fits(G, T); }
 inline int rp2_chunks(int M, int G, int T) { (void)G; const int n = (M * T * 16 + 63) / 64; return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : n <= 8 ? 8 : 0; }   // x chunks per lane, M > 1
 inline size_t rp2_lds(int M, int G, int T, bool norm = false) {
   return (size_t)16 * M * 16 * G * sizeof(float) + (size_t)16 * ((size_t)M * (T * 128 + 8) * 2 + (size_t)G * T * 64 + 16) +
@@ -642,7 +645,7 @@ inline size_t rp2_lds(int M, int G, int T, bool norm = false) {
 
 template <int G, int T, int EPI, bool NORM>
 static bool rp2_launch_t(const GemmArgs& a, const void* packed, int NG, int chunks, int depth, int nwg, size_t lds) {
-  if constexpr (!rp2_fits(G, T) || (EPI == 1 && (G & 1))) {
+  if constexpr ((!rp2_fits(G, T) && !(rp2_fits_long(G, T) && EPI == 0 && !NORM)) || (EPI == 1 && (G & 1))) {
     return false;
   } else {
     const u32x4_t* qw_r = (const u32x4_t*)packed;
@@ -671,7 +674,18 @@ static bool rp2_launch_t(const GemmArgs& a, const void* packed, int NG, int chun
       return true;                                                                                                                 \
     } while (0)
     static const bool env_m1 = !(getenv("AWQ_RP2_M1") && atoi(getenv("AWQ_RP2_M1")) == 0);   // A/B knob
-    if constexpr (NORM) {                                // x chunk layout of the generic form at every M (chunks = x chunks per lane)
+    if constexpr (!rp2_fits(G, T)) {                     // the long form exists for one row only
+      constexpr int C1 = (T * 16 + G * T * 4 + 63) / 64;            // <= 6 for G T <= 32, T <= 16
+      constexpr int CH1 = C1 <= 1 ? 1 : C1 <= 2 ? 2 : C1 <= 4 ? 4 : 8;
+      if (a.M == 1 && a.moe_slots == 0) {
+#ifdef AWQ_LAB
+        if (depth == 3) RP2_GO(CH1, 3, true, false);       // ring depth A/B (AWQ_RP2_D)
+        if (depth == 4) RP2_GO(CH1, 4, true, false);
+        if (depth == 6) RP2_GO(CH1, 6, true, false);
+#endif
+        RP2_GO(CH1, 2, true, false);
+      }
+    } else if constexpr (NORM) {                                // x chunk layout of the generic form at every M (chunks = x chunks per lane)
       if (a.M == 1 && chunks == 1) RP2_GO(1, 2, true, true);
       if (chunks == 1) RP2_GO(1, 2, false, true);
       if (chunks == 2) RP2_GO(2, 2, false, true);
@@ -713,8 +727,22 @@ static bool rp2_launch_g(int T, const GemmArgs& a, const void* packed, int NG, i
     case 6: return rp2_launch_t<G, 6, EPI, NORM>(a, packed, NG, chunks, depth, nwg, lds);
     case 7: return rp2_launch_t<G, 7, EPI, NORM>(a, packed, NG, chunks, depth, nwg, lds);
     case 8: return rp2_launch_t<G, 8, EPI, NORM>(a, packed, NG, chunks, depth, nwg, lds);
-    default: return false;
+    default: break;
   }
+  if constexpr (EPI == 0 && !NORM) {
+    switch (T) {
+      case 9: return rp2_launch_t<G, 9, EPI, NORM>(a, packed, NG, chunks, depth, nwg, lds);
+      case 10: return rp2_launch_t<G, 10, EPI, NORM>(a, packed, NG, chunks, depth, nwg, lds);
+      case 11: return rp2_launch_t<G, 11, EPI, NORM>(a, packed, NG, chunks, depth, nwg, lds);
+      case 12: return rp2_launch_t<G, 12, EPI, NORM>(a, packed, NG, chunks, depth, nwg, lds);
+      case 13: return rp2_launch_t<G, 13, EPI, NORM>(a, packed, NG, chunks, depth, nwg, lds);
+      case 14: return rp2_launch_t<G, 14, EPI, NORM>(a, packed, NG, chunks, depth, nwg, lds);
+      case 15: return rp2_launch_t<G, 15, EPI, NORM>(a, packed, NG, chunks, depth, nwg, lds);
+      case 16: return rp2_launch_t<G, 16, EPI, NORM>(a, packed, NG, chunks, depth, nwg, lds);
+      default: break;
+    }
+  }
+  return false;
 }
 
 // launches gemv_rp2_kernel if an instantiation exists for (G, T = per-wave k-blocks at 16 waves, M); false = nothing enqueued

@@ -364,7 +364,7 @@ extern "C" int awq_aux_moe_gemv_blocks(const void* x, int64_t ldx, int x_div, co
     return AWQ_ERR_BAD_SHAPE;
   if ((((uintptr_t)packed_experts) & 15) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 1) || (expert_stride_bytes & 15) || ldx % 8)
     return AWQ_ERR_MISALIGNED;
-  if (!repacked_fast(K, N, group_size, dtype) || K / 128 < 16 || K / 128 >= 4096 || group_size / 128 >= 4096 || (silu_mul && N % 32)) return AWQ_ERR_BAD_VARIANT;
+  if (!repacked_fast(K, N, group_size, dtype) || K / 128 >= 4096 || group_size / 128 >= 4096 || (silu_mul && N % 32)) return AWQ_ERR_BAD_VARIANT;
   GemmArgs a;
   a.x = x; a.ldx = ldx; a.qweight = nullptr; a.scales = nullptr; a.qzeros = nullptr; a.bias = nullptr; a.y = y;
   a.workspace = nullptr; a.workspace_bytes = 0;

@@ -14,6 +14,7 @@ weight_utils.py:1108-1137).
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -92,7 +93,17 @@ class LlamaDecoderLayer(torch.nn.Module):
         self.register_buffer("v_cache", torch.zeros(max_batch, self.num_kv_heads, max_seq, self.head_dim, dtype=dtype), persistent=False)
 
     FUSE_NORM_MAX_BATCH = 16
+    FUSE_NORM = os.environ.get("SGLANG_AWQ_AMD_FOLD_NORM", "1") != "0"      # 0: the reference's norm order at every batch size
     attn_splits = 1            # workgroups per (sequence, head) in the decode attention; GraphedDecoder sets it from batch / context
+
+    def norm_order(self, batch: int) -> str:
+        """Which arithmetic order the RMSNorm in front of qkv_proj / gate_up_proj runs in at this batch size (reported by the
+        benchmarks next to their tok/s): "folded" = inv_rms * ((v * w) W), the norm carried through the GEMV's linearity
+        (gemv_rp2_kernel<NORM>; differs from the reference's order by where x is rounded, at most an fp16 ulp of x per element);
+        "reference" = fp16(fp16(v * inv_rms) * w) W as models/llama.py:277-290 -> layernorm.py computes it (a separate norm launch)."""
+        folded = (self.FUSE_NORM and batch <= self.FUSE_NORM_MAX_BATCH and getattr(self.qkv_proj, "awq_packed", None) is not None
+                  and self.qkv_proj.bias is None)
+        return "folded: inv_rms * ((v * w) W)" if folded else "reference: fp16(fp16(v * inv_rms) * w) W"
 
     @staticmethod
     def _awq_dims(lin):
@@ -126,7 +137,7 @@ class LlamaDecoderLayer(torch.nn.Module):
         # 14.5 for the earlier prologue form and ~4.7 us for a separate norm launch; the SiLU-mul epilogue is free at every batch
         # size.  The folded form exists up to 4 staging chunks per lane (8 rows at K = 4096, 4 at K = 8192); beyond that the call
     # returns None and the norm is its own launch (as it is past 16 rows, where the GEMV runs two row tiles per fragment).
-        fuse_norm = B <= self.FUSE_NORM_MAX_BATCH
+        fuse_norm = self.FUSE_NORM and B <= self.FUSE_NORM_MAX_BATCH
         qkv = None
         packed = getattr(self.qkv_proj, "awq_packed", None)
         if fuse_norm and packed is not None and self.qkv_proj.bias is None:
@@ -295,6 +306,17 @@ class GraphedDecoder:
         s.wait_stream(torch.cuda.current_stream())
         if self.start_pos + self.steps_taken + warmup > self.model.max_seq:
             raise ValueError("not enough room in the KV cache for the warm-up steps")
+        # the per-(device, stream) scratch of the split-K GEMV and the split-S attention is created eagerly, before anything is
+        # captured on `s` (a first use inside the capture would raise: ops._workspace) — also with warmup = 0
+        from . import _lib, aux_ops, ops
+
+        layer0 = self.model.layers[0]
+        dev = self.tokens.device
+        ops.prepare_stream_workspaces(s, dev)
+        if layer0.attn_splits > 1:
+            need = _lib.load().awq_aux_decode_attention_workspace_bytes(self.batch, layer0.num_heads, layer0.head_dim, layer0.attn_splits)
+            aux_ops.prepare_attention_workspace(dev, s.cuda_stream, need)
+            torch.cuda.current_stream(dev).synchronize()
         with torch.cuda.stream(s):
             for _ in range(warmup):
                 self._step()

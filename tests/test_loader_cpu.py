@@ -22,9 +22,14 @@ HF = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_atten
           vocab_size=128, rms_norm_eps=1e-5, rope_theta=10000.0, max_position_embeddings=64)
 
 
-def _write_checkpoint(path, quant_in_config=True):
+def _write_checkpoint(path, quant_in_config=True, biases=None):
+    """biases: None, "qwen2" (q / k / v biases, model_type qwen2) or "llama" (attention_bias + mlp_bias: every projection)."""
     os.makedirs(path, exist_ok=True)
     hf = dict(HF)
+    if biases == "qwen2":
+        hf["model_type"] = "qwen2"
+    elif biases == "llama":
+        hf["attention_bias"], hf["mlp_bias"] = True, True
     q = {"quant_method": "awq", "bits": 4, "group_size": 128, "zero_point": True, "version": "gemm"}
     if quant_in_config:
         hf["quantization_config"] = q
@@ -51,6 +56,9 @@ def _write_checkpoint(path, quant_in_config=True):
             base = f"model.layers.{li}.{mod}"
             tensors[base + ".qweight"], tensors[base + ".scales"], tensors[base + ".qzeros"] = _t(qw), _t(s), _t(qz)
             truth[base] = (qw, s, qz)
+            if biases == "llama" or (biases == "qwen2" and mod in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj")):
+                tensors[base + ".bias"] = _t(synth.make_bias(N, "f16", 7 * li + i))
+                truth[base + ".bias"] = tensors[base + ".bias"].numpy()
         tensors[f"model.layers.{li}.input_layernorm.weight"] = torch.rand(HF["hidden_size"]).half()
         tensors[f"model.layers.{li}.post_attention_layernorm.weight"] = torch.rand(HF["hidden_size"]).half()
         tensors[f"model.layers.{li}.self_attn.rotary_emb.inv_freq"] = torch.rand(head // 2)      # must be skipped
@@ -125,3 +133,42 @@ def test_loader_rejects_non_awq_and_missing_config(tmp_path):
         load_quant_config(str(tmp_path))
     with pytest.raises(ValueError, match="safetensors"):
         list(iterate_safetensors(str(tmp_path)))
+
+
+@pytest.mark.parametrize("biases", ["qwen2", "llama"])
+def test_bias_tensors_load_and_shard(tmp_path, biases):
+    """`*.bias` names go through the stacked mapping and the parameters' weight loaders like the weights (reference:
+    linear.py:348-358, 1286-1293 — `output_dim: 0` for column-parallel layers, replicated for row-parallel ones).  TP = 1: the
+    fused qkv / gate_up biases are the concatenations; rank 1 of 2: q by heads, k / v by KV heads, gate / up by halves, the
+    o_proj / down_proj biases whole (rank 0 alone adds them, linear.py:1401)."""
+    from sglang_awq_amd.llama import LlamaForCausalLM
+
+    torch.manual_seed(2)
+    _, truth = _write_checkpoint(str(tmp_path), biases=biases)
+    cfg = load_llama_config(str(tmp_path))
+    assert cfg.qkv_bias and cfg.o_bias == (biases == "llama") and cfg.mlp_bias == (biases == "llama")
+    model = load_llama_awq(str(tmp_path), device=None, max_batch=1, max_seq=8)
+    b = lambda li, mod: truth[f"model.layers.{li}.{mod}.bias"]
+    for li, layer in enumerate(model.layers):
+        want = np.concatenate([b(li, f"self_attn.{n}_proj") for n in "qkv"])
+        assert np.array_equal(layer.qkv_proj.bias.numpy(), want)
+        if biases == "llama":
+            assert np.array_equal(layer.o_proj.bias.numpy(), b(li, "self_attn.o_proj"))
+            assert np.array_equal(layer.gate_up_proj.bias.numpy(), np.concatenate([b(li, "mlp.gate_proj"), b(li, "mlp.up_proj")]))
+            assert np.array_equal(layer.down_proj.bias.numpy(), b(li, "mlp.down_proj"))
+        else:
+            assert layer.o_proj.bias is None and layer.gate_up_proj.bias is None and layer.down_proj.bias is None
+    tpd.set_tensor_parallel_group(tpd.TensorParallelGroup(None, 1, 2))
+    try:
+        m2 = LlamaForCausalLM(cfg, load_quant_config(str(tmp_path)), max_batch=1, max_seq=8)
+        stats = load_weights(m2, iterate_safetensors(str(tmp_path)))
+    finally:
+        tpd.set_tensor_parallel_group(tpd.TensorParallelGroup(None, 0, 1))
+    assert stats["skipped"] == HF["num_hidden_layers"]                    # only the rotary inv_freq tensors: no bias was dropped
+    layer = m2.layers[1]
+    want = np.concatenate([b(1, "self_attn.q_proj")[128:256], b(1, "self_attn.k_proj")[64:128], b(1, "self_attn.v_proj")[64:128]])
+    assert np.array_equal(layer.qkv_proj.bias.numpy(), want)
+    if biases == "llama":
+        assert np.array_equal(layer.gate_up_proj.bias.numpy(), np.concatenate([b(1, "mlp.gate_proj")[256:512], b(1, "mlp.up_proj")[256:512]]))
+        assert np.array_equal(layer.o_proj.bias.numpy(), b(1, "self_attn.o_proj"))          # replicated
+        assert np.array_equal(layer.down_proj.bias.numpy(), b(1, "mlp.down_proj"))
