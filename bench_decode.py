@@ -26,7 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def measure(model_name: str, batches, steps: int = 64, context: int = 1024, dev=None, verbose: bool = False):
+def measure(model_name: str, batches, steps: int = 64, context: int = 1024, dev=None, verbose: bool = False, layers=None):
     """Decode tok/s of a synthetic Llama-AWQ model per batch size: median over `steps` single-step latencies, each bracketed by
     torch.cuda.synchronize (the method of the reference's bench_one_batch.py:497-623), plus the device-only time of the same
     step (16 graph replays back to back between HIP events).  Returns one dict per batch size."""
@@ -46,6 +46,8 @@ def measure(model_name: str, batches, steps: int = 64, context: int = 1024, dev=
     else:
         cfg = LlamaConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=4, num_attention_heads=8, num_key_value_heads=8,
                           vocab_size=2048)
+    if layers:
+        cfg.num_hidden_layers = int(layers)           # a shortened stack (rehearsals, tests): per-layer work and collectives unchanged
     max_seq = context + steps + 32
     with torch.device(dev):
         model = LlamaForCausalLM(cfg, AWQConfig(4, 128, True), max_batch=max(batches), max_seq=max_seq)
@@ -59,7 +61,13 @@ def measure(model_name: str, batches, steps: int = 64, context: int = 1024, dev=
     name = {"7b": "Llama-2-7B-AWQ", "70b": "Llama-2-70B-AWQ", "tiny": "tiny-llama"}[model_name]
     results = []
     for B in batches:
-        dec = GraphedDecoder(model, B, start_pos=context).capture(warmup=2)
+        dec = GraphedDecoder(model, B, start_pos=context)
+        if os.environ.get("BENCH_TEST_BACKEND"):
+            # rehearsal over gloo: a gloo collective cannot be captured (and a failed capture poisons the stream): step eagerly, say so
+            dec._set_attention_splits()
+            dec.capture_error = f"not captured: rehearsal backend {os.environ['BENCH_TEST_BACKEND']}"
+        else:
+            dec.capture(warmup=2)
         dec.run(3)
         lat = []
         for _ in range(steps):
@@ -131,6 +139,7 @@ def main():
     ap.add_argument("--context", type=int, default=1024,
                     help="KV positions already in the cache when timing starts (bench_one_batch.py defaults to 1024 input tokens)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--layers", type=int, default=0, help="run only this many decoder layers (0 = the model's own count)")
     args = ap.parse_args()
 
     import torch
@@ -140,11 +149,19 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    # BENCH_TEST_BACKEND=gloo + BENCH_TEST_ONE_DEVICE=1: rehearsal of the N > 1 path on a one-GPU box (every rank on device 0,
+    # collectives over gloo; graph capture of a gloo collective fails, so the decoder steps eagerly and says so).  Never for reported numbers.
+    test_backend = os.environ.get("BENCH_TEST_BACKEND")
+    dev = torch.device("cuda", 0 if os.environ.get("BENCH_TEST_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
-    init_tensor_parallel(backend="nccl", device=dev) if world > 1 else init_tensor_parallel()
+    if world > 1:
+        init_tensor_parallel(backend=test_backend or "nccl", device=None if test_backend else dev)
+    else:
+        init_tensor_parallel()
+    if os.environ.get("BENCH_TEST_FAIL_RANK") == str(rank):
+        raise SystemExit(f"rank {rank}: injected failure (BENCH_TEST_FAIL_RANK)")       # a rank's failure must end the job non-zero
     batches = [int(b) for b in args.batches.split(",")]
-    results = measure(args.model, batches, args.steps, args.context, dev, verbose=(rank == 0))
+    results = measure(args.model, batches, args.steps, args.context, dev, verbose=(rank == 0), layers=args.layers)
     cfg = {"7b": LlamaConfig.llama2_7b, "70b": LlamaConfig.llama2_70b}.get(args.model, lambda: LlamaConfig(
         hidden_size=512, intermediate_size=1024, num_hidden_layers=4, num_attention_heads=8, num_key_value_heads=8, vocab_size=2048))()
 

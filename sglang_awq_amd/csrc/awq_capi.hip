@@ -32,7 +32,7 @@ static int repacked_dispatch(const GemmArgs& a, const void* packed) {
   // would leave most CUs idle (4096 x 11008: 13.6 us per pass vs ~62 us for one round of under-filled tiles).  Where the
   // wide tiles are few (narrow matrices, up to 512 rows) 128 x 64 tiles with the K split inside the workgroup fill the
   // chip better (11008 x 4096 at M = 256: 142 -> 90 us); beyond that the hand-pipelined wide tiles.
-  static const int env_mid = getenv("AWQ_MID") ? atoi(getenv("AWQ_MID")) : 1;      // A/B knob: 0 = never the 128 x 64 tiles
+  static const int env_mid = lab_env("AWQ_MID", 1);      // lab knob: 0 = never the 128 x 64 tiles
   if (M <= 32) {
     if (M > 8 && a.workspace != nullptr) {             // narrow matrix, many rows: wide strips with K split across workgroups
       const int rs = launch_gemv_repacked_splitk(a, packed);

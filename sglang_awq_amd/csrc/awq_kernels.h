@@ -3,12 +3,22 @@
 
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "../../include/awq_hip.h"
 #include "awq_device.h"
 
 namespace awq {
+
+// A/B knobs of the laboratory build (make EXTRA=-DAWQ_LAB; tools/ab_*.sh, tools/kbench): environment variables that force a
+// kernel variant.  The product library reads no environment: every lab_env() folds to its default, which is the measured choice
+// recorded in DESIGN.md.
+#ifdef AWQ_LAB
+inline int lab_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+constexpr int lab_env(const char*, int dflt) { return dflt; }
+#endif
 
 struct GemmArgs {
   const void* x;

@@ -158,7 +158,7 @@ int launch_repack(const int32_t* qweight, const void* scales, const int32_t* qze
   const int NG = rp_groups(N), C = (int)(N / 8);
   uint32_t* qw_r = (uint32_t*)packed;
   uint32_t* zs_r = qw_r + (size_t)NG * (K / 128) * 256;
-  static const int env_simple = getenv("AWQ_REPACK_SIMPLE") ? atoi(getenv("AWQ_REPACK_SIMPLE")) : 0;      // A/B knob
+  static const int env_simple = lab_env("AWQ_REPACK_SIMPLE", 0);      // lab knob
   if (env_simple)
     hipLaunchKernelGGL(repack_qweight_kernel, dim3(2048), dim3(256), 0, stream, (const uint32_t*)qweight, qw_r, (int)K, C, NG);
   else
@@ -173,7 +173,7 @@ int launch_repack(const int32_t* qweight, const void* scales, const int32_t* qze
 unsigned long long* g_rp_stamp_buffer = nullptr;
 extern "C" void awq_debug_set_stamp_buffer(void* p) { g_rp_stamp_buffer = (unsigned long long*)p; }
 
-static int rp_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static int rp_env(const char* name, int dflt) { return lab_env(name, dflt); }
 
 bool gemv_strip_geometry(int64_t K, int64_t N, int* G, int* nwg) {
   (void)K;

@@ -1,7 +1,7 @@
 // Fused variants of the repacked decode GEMV for the decode harness (C entry in awq_aux.h):
-//   * norm prologue   x = RMSNorm(h + delta) * w   (the reference's RMSNorm-with-residual before qkv_proj /
-//                     gate_up_proj, python/sglang/srt/models/llama.py:277-290), computed by every workgroup in LDS
-//                     while its weight loads are in flight — removes a ~4.7 us dependent launch per use;
+//   * folded norm     y = inv_rms(v) * ((v * w) W), v = h + delta   (the reference's RMSNorm-with-residual before qkv_proj /
+//                     gate_up_proj, python/sglang/srt/models/llama.py:277-290, carried through the GEMV's linearity:
+//                     gemv_rp2_kernel<NORM>) — removes a ~4.7 us dependent launch per use;
 //   * SiLU-mul epilogue  act = silu(gate) * up   (layers/activation.py SiluAndMul after gate_up_proj) on a copy
 //                     repacked from column-interleaved gate / up groups, so both halves of a pair sit in one strip.
 // Same kernel template as the plain operator (awq_repacked_gemv.h); only 16-wave, straight-line, one-row-tile
@@ -13,9 +13,9 @@
 
 namespace awq {
 
-template <int PRO, int EPI>
+template <int EPI>
 static bool fused_go(int G, const GemmArgs& a, const void* packed, int NG, int per_wave, int T, int nwg, size_t lds) {
-  return rp_launch_g<16, true, 1, PRO, EPI>(G, a, packed, NG, per_wave, T, nwg, lds);
+  return rp_launch_g<16, true, 1, EPI>(G, a, packed, NG, per_wave, T, nwg, lds);
 }
 
 int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed) {
@@ -32,7 +32,7 @@ int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed) {
     const int T2 = (pw == 4 && rp_fits(8, 2, G2, 4)) ? 4 : 0;
     const size_t lds2 = (size_t)8 * a.M * 16 * G2 * sizeof(float);
     if (lds2 > (size_t)kRpMaxLds) return AWQ_ERR_BAD_VARIANT;
-    if (!rp_launch_g<8, true, 2, 0, 1>(G2, a, packed, NG2, pw, T2, (NG2 + G2 - 1) / G2, lds2)) return AWQ_ERR_BAD_VARIANT;
+    if (!rp_launch_g<8, true, 2, 1>(G2, a, packed, NG2, pw, T2, (NG2 + G2 - 1) / G2, lds2)) return AWQ_ERR_BAD_VARIANT;
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
   }
   if (!norm && (((uintptr_t)a.x) & 15)) return AWQ_ERR_BAD_VARIANT;
@@ -46,43 +46,26 @@ int launch_gemv_repacked_fused(const GemmArgs& a, const void* packed) {
     // launcher does, with the SiLU-mul epilogue (a strip holds two (gate, up) pairs)
     const int pw = (KB + 7) / 8;
     const size_t lds_r = (size_t)8 * a.M * 16 * 4 * sizeof(float);
-    if (!rp_launch<4, 8, true, 1, 0, 1>(a, packed, NG, pw, 0, (NG + 3) / 4, lds_r)) return AWQ_ERR_BAD_VARIANT;
+    if (!rp_launch<4, 8, true, 1, 1>(a, packed, NG, pw, 0, (NG + 3) / 4, lds_r)) return AWQ_ERR_BAD_VARIANT;
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
   }
   if (G > kRpMaxG || G > NG) return AWQ_ERR_BAD_VARIANT;
   const int nwg = (NG + G - 1) / G;
   const int T = (KB + W - 1) / W;                                            // = per_wave: straight-line variants only
-  int PRO = 0;
   if (norm) {
     if (!a.norm_delta || !a.norm_w || !a.norm_h_out || a.norm_h_out == a.norm_h) return AWQ_ERR_BAD_VARIANT;
     if ((((uintptr_t)a.norm_h) | ((uintptr_t)a.norm_delta) | ((uintptr_t)a.norm_w) | ((uintptr_t)a.norm_h_out)) & 15) return AWQ_ERR_BAD_VARIANT;
-    const int per_lane = (a.M * T * 16 + 63) / 64;                           // chunks of 8 halves per lane of a wave's own columns
-    PRO = per_lane <= 1 ? 1 : per_lane <= 2 ? 2 : per_lane <= 4 ? 4 : 0;
   }
-  size_t lds = (size_t)W * a.M * 16 * G * sizeof(float);
-  // the restructured kernel (gemv_rp2_kernel: norm folded through the GEMV, SiLU-mul epilogue) wherever it has an instantiation;
-  // AWQ_RP2_NORM=0: the earlier prologue form (A/B)
-  static const bool env_norm2 = !(getenv("AWQ_RP2_NORM") && atoi(getenv("AWQ_RP2_NORM")) == 0);
-  if (!norm || env_norm2) {
-    const bool ok = norm ? (a.silu_mul ? rp2_launch<1, true>(G, T, a, packed, NG, 2, nwg) : rp2_launch<0, true>(G, T, a, packed, NG, 2, nwg))
-                         : rp2_launch<1, false>(G, T, a, packed, NG, 2, nwg);        // (!norm && !silu_mul went to the plain launcher above)
-    if (ok) return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
-  }
-  if ((norm && !PRO) || !rp_fits_fused(G, T, PRO, a.silu_mul)) return AWQ_ERR_BAD_VARIANT;
-  if (norm) lds += (size_t)W * a.M * (T * 128 + 8) * 2 + (size_t)W * PRO * 4 * sizeof(float);
+  // gemv_rp2_kernel (norm folded through the GEMV and / or SiLU-mul epilogue) wherever it has an instantiation
+  const bool ok = norm ? (a.silu_mul ? rp2_launch<1, true>(G, T, a, packed, NG, 2, nwg) : rp2_launch<0, true>(G, T, a, packed, NG, 2, nwg))
+                       : rp2_launch<1, false>(G, T, a, packed, NG, 2, nwg);        // (!norm && !silu_mul went to the plain launcher above)
+  if (ok) return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+  // no folded-norm instantiation (more than 4 staging chunks per lane): the caller runs the norm as its own launch.  The SiLU-mul
+  // epilogue alone also exists on the round-1 kernel template (deeper K per wave than the straight-line form holds)
+  if (norm || !rp_fits_fused(G, T, a.silu_mul)) return AWQ_ERR_BAD_VARIANT;
+  const size_t lds = (size_t)W * a.M * 16 * G * sizeof(float);
   if (lds > (size_t)kRpMaxLds) return AWQ_ERR_BAD_VARIANT;
-  bool launched;
-  if (a.silu_mul) {
-    if (PRO == 0) launched = fused_go<0, 1>(G, a, packed, NG, T, T, nwg, lds);
-    else if (PRO == 1) launched = fused_go<1, 1>(G, a, packed, NG, T, T, nwg, lds);
-    else if (PRO == 2) launched = fused_go<2, 1>(G, a, packed, NG, T, T, nwg, lds);
-    else launched = fused_go<4, 1>(G, a, packed, NG, T, T, nwg, lds);
-  } else {
-    if (PRO == 1) launched = fused_go<1, 0>(G, a, packed, NG, T, T, nwg, lds);
-    else if (PRO == 2) launched = fused_go<2, 0>(G, a, packed, NG, T, T, nwg, lds);
-    else launched = fused_go<4, 0>(G, a, packed, NG, T, T, nwg, lds);
-  }
-  if (!launched) return AWQ_ERR_BAD_VARIANT;
+  if (!fused_go<1>(G, a, packed, NG, T, T, nwg, lds)) return AWQ_ERR_BAD_VARIANT;
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 

@@ -76,11 +76,10 @@ __device__ __forceinline__ void rp_compute(const RpBlock& b, float4_t (&acc)[kRp
 }
 
 // Optional fusions for the decode harness (awq_aux.h: awq_aux_gemv_repacked_fused).
-//   PRO = chunks of 8 halves per lane (1, 2 or 4; M * T * 16 <= 64 * PRO): x is not read; every wave builds
-//         x = rmsnorm(h + delta) * w for the columns of its own k-blocks (see the prologue in the kernel);
-//         workgroup 0 also stores h + delta.  Same arithmetic as add_rmsnorm_kernel: fp16 add, fp32 sum of squares, fp16(v * inv) * w.
 //   EPI = 1: column groups alternate gate / up (repacked from column-interleaved tensors); the epilogue writes
 //         act = fp16(silu(fp16 gate)) * fp16 up, [M, N / 2], instead of y.
+// (The RMSNorm in front of a linear is folded through gemv_rp2_kernel<NORM>; the round-1 form — a norm prologue in this kernel,
+// every workgroup re-reading all of h + delta behind a barrier — measured 1.6 .. 6.5 us slower and was removed in round 3.)
 struct RpFuse {
   const half_t* h;
   const half_t* delta;
@@ -102,14 +101,13 @@ struct RpFuse {
 
 // T = k-blocks per wave when it is small enough to issue every load up front (straight-line code, exact
 // counted waits); T == 0: any count, double-buffered loop.
-template <int G, int T, int W, bool NT, int MT, int PRO = 0, int EPI = 0>
+template <int G, int T, int W, bool NT, int MT, int EPI = 0>
 __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(const uint16_t* __restrict__ x, int64_t ldx,
                                                                           const u32x4_t* __restrict__ qw_r,
                                                                           const uint32_t* __restrict__ zs_r,
                                                                           const void* __restrict__ bias, void* __restrict__ y,
                                                                           int M, int K, int N, int g, int NG, int per_wave,
                                                                           unsigned long long* __restrict__ dbg, RpFuse fz) {
-  static_assert(PRO >= 0 && (PRO == 0 || (T > 0 && MT == 1)), "the norm prologue exists for the straight-line single-tile variants");
   extern __shared__ __attribute__((aligned(16))) float red[];    // [W][M][16 G]
 #define RP_STAMP(slot) do { if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   RP_STAMP(0);
@@ -135,96 +133,15 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
 
   if constexpr (T > 0) {
     RpBlock buf[T];
-    // PRO != 0: this wave's x columns live in wave-private LDS, [M][T * 128 (+8 halves: rows 16 B apart in bank phase)]
-    half_t* const x_lds = (half_t*)(red + (size_t)W * M * 16 * G) + (size_t)wave * M * (T * 128 + 8);
-    constexpr int XS = T * 128 + 8;
-    if constexpr (PRO > 0) {
-      // Norm prologue.  Each wave owns the columns of its own k-blocks (T x 128) of every row: it loads h, delta
-      // and w for them, adds, and contributes per-row sums of squares; ONE workgroup barrier later every wave has
-      // the row sums, issues its weight loads, and normalises its own columns under their latency (wave-private
-      // LDS round trip into the MFMA fragment order, no second barrier).  Two rules found by measurement:
-      //  * the prologue loads must complete before any weight load is issued: with the weight stream of every
-      //    workgroup of the XCD queued in the L2 these few KB take ~3 us instead of ~0.4;
-      //  * no workgroup barrier after the weight loads: load ISSUE of the later waves is throttled by the saturated
-      //    memory pipeline, so a barrier there holds every wave until nearly all of the strip has arrived.
-      typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
-      constexpr int CH = PRO;                                            // chunks of 8 halves per lane: M * T * 16 <= 64 * CH
-      constexpr int WC = T * 16;                                         // chunks per row in this wave's column range
-      float* part = (float*)((half_t*)(red + (size_t)W * M * 16 * G) + (size_t)W * M * (T * 128 + 8));   // [M][W]
-      const int col0 = kb_begin * 128;                                   // first column owned by this wave
-      h8_t hv[CH], dv[CH], wv[CH];
-      int crow[CH], ccol[CH];
-      bool cok[CH];
-#pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        const int c = lane + i * 64;
-        crow[i] = c / WC;
-        ccol[i] = (c - crow[i] * WC) * 8;                                // column offset inside the wave's range
-        cok[i] = crow[i] < M && col0 + ccol[i] < K;
-        const int gr = cok[i] ? crow[i] : 0, gc = cok[i] ? col0 + ccol[i] : 0;     // clamped: loaded, then masked
-        hv[i] = *(const h8_t*)(fz.h + (size_t)gr * ldx + gc);
-        dv[i] = *(const h8_t*)(fz.delta + (size_t)gr * ldx + gc);
-        wv[i] = *(const h8_t*)(fz.w + gc);
-      }
-#pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        hv[i] = hv[i] + dv[i];                                           // fp16 add, as the eager h = h + delta
-        float ss = 0.f;
-        if (cok[i]) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) ss += (float)hv[i][e] * (float)hv[i][e];
-        }
-        // a row's WC chunks sit in WC consecutive lanes (WC = 16, 32, 48 or 64): segmented sum over aligned groups of 16,
-        // then the group leaders of one row add up in LDS order below
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-        if ((lane & 15) == 0) part[(wave * CH + i) * 4 + (lane >> 4)] = ss;   // [W][CH][4 sixteen-lane groups]
-      }
-      __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const int kb = kb_begin + t < KB ? kb_begin + t : KB - 1;         // clamped: re-read, then weighted by x = 0
-        rp_load<G, NT, MT, false>(buf[t], qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      RP_STAMP(1);
-#pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        if (cok[i]) {
-          // sum of squares of row crow[i]: every (wave, chunk slot, 16-lane group) that belongs to that row, fixed order
-          float tot = 0.f;
-          for (int w2 = 0; w2 < W; ++w2)
-#pragma unroll
-            for (int i2 = 0; i2 < CH; ++i2) {
-              const float4_t p4 = *(const float4_t*)(part + (w2 * CH + i2) * 4);
-#pragma unroll
-              for (int g4 = 0; g4 < 4; ++g4)
-                if ((g4 * 16 + i2 * 64) / WC == crow[i]) tot += p4[g4];
-            }
-          const float inv = __builtin_amdgcn_rsqf(tot / (float)K + fz.eps);
-          h8_t o;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)hv[i][e] * inv) * wv[i][e];
-          *(h8_t*)(x_lds + (size_t)crow[i] * XS + ccol[i]) = o;
-          if (blockIdx.x == 0) *(h8_t*)(fz.h_out + (size_t)crow[i] * ldx + col0 + ccol[i]) = hv[i];
-        }
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const int kb = kb_begin + t < KB ? kb_begin + t : KB - 1;         // clamped: re-read, then weighted by x = 0
-        rp_load<G, NT, MT, true>(buf[t], qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      RP_STAMP(1);
-    }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      if constexpr (PRO != 0) {                            // fragments of this k-block only: 16 registers live at a time
+      const int kb = kb_begin + t < KB ? kb_begin + t : KB - 1;         // clamped: re-read, then weighted by x = 0
+      rp_load<G, NT, MT, true>(buf[t], qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    RP_STAMP(1);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) buf[t].xa[d][0] = *(const u32x4_t*)(x_lds + (size_t)xr[0] * XS + t * 128 + d * 32 + q * 8);
-      }
+    for (int t = 0; t < T; ++t) {
       if (kb_begin + t >= KB) {
 #pragma unroll
         for (int d = 0; d < 4; ++d)
@@ -332,7 +249,7 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
 // x' is staged as v * (w / 64) and the epilogue multiplies by 64 inv_rms: exact (powers of two) wherever v w and w / 64 are normal
 // fp16 numbers, and finite for |v w| up to 4e6 — residual streams with massive activations (1e3..1e4 in a few channels of
 // Llama-family models) times a norm weight above 1 would overflow the un-scaled product.
-// The earlier norm prologue (gemv_repacked_kernel, PRO > 0) needed every workgroup to re-read all of h + delta and one
+// The earlier norm prologue (round 1, inside gemv_repacked_kernel; removed) needed every workgroup to re-read all of h + delta and one
 // workgroup barrier before its weight loads: +1.6 us at M = 1, +6.5 at M = 8; this form costs two extra staging loads.
 #ifndef RP2_CMAJOR
 #define RP2_CMAJOR 1          // unit i = (c = i / T, t = i % T): a wave's consecutive loads are contiguous, and the first third of what a
@@ -673,7 +590,7 @@ static bool rp2_launch_t(const GemmArgs& a, const void* packed, int NG, int chun
                          a.bias, a.y, a.M, a.K, a.N, a.K / a.g, gmul, gshift, NG, fz);                                              \
       return true;                                                                                                                 \
     } while (0)
-    static const bool env_m1 = !(getenv("AWQ_RP2_M1") && atoi(getenv("AWQ_RP2_M1")) == 0);   // A/B knob
+    static const bool env_m1 = lab_env("AWQ_RP2_M1", 1) != 0;   // lab knob
     if constexpr (!rp2_fits(G, T)) {                     // the long form exists for one row only
       constexpr int C1 = (T * 16 + G * T * 4 + 63) / 64;            // <= 6 for G T <= 32, T <= 16
       constexpr int CH1 = C1 <= 1 ? 1 : C1 <= 2 ? 2 : C1 <= 4 ? 4 : 8;
@@ -775,21 +692,14 @@ constexpr bool rp_fits(int W, int MT, int G, int T) {
 }
 
 
-// The fused variants exist for 16 waves, non-temporal loads, one row tile, T = 1..4.  The norm prologue's x
-// fragments arrive late (from LDS, after the weight loads were issued), so it needs no more registers than the
-// plain kernel (tools/rp_resources.py lists them too).
-constexpr bool rp_fits_xl(int G, int T);
-constexpr bool rp_fits_fused(int G, int T, int PRO, int EPI) {
+// The SiLU-mul epilogue variants of this kernel exist for 16 waves, non-temporal loads, one row tile, T = 1..4.
+constexpr bool rp_fits_fused(int G, int T, int EPI) {
   if (EPI && (G & 1)) return false;
-  if (PRO > 0) return rp_fits_xl(G, T) && !(PRO >= 2 && G == 8 && T == 2);      // x fragments come lazily from LDS: 5 G registers per k-block
   return T >= 1 && T <= 4 && rp_fits(16, 1, G, T);
 }
 
-// x staged through wave-private LDS (PRO < 0), 16 waves: T k-blocks of 5 G registers each (tools/rp_resources.py)
-constexpr bool rp_fits_xl(int G, int T) { return T >= 1 && T <= 8 && G * T <= 16; }
-
-// returns false when no instantiation exists for (G, T, W, MT, PRO, EPI) or the LDS opt-in failed: nothing was enqueued
-template <int G, int W, bool NT, int MT, int PRO, int EPI>
+// returns false when no instantiation exists for (G, T, W, MT, EPI) or the LDS opt-in failed: nothing was enqueued
+template <int G, int W, bool NT, int MT, int EPI>
 static bool rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wave, int T, int nwg, size_t lds) {
   const u32x4_t* qw_r = (const u32x4_t*)packed;
   const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
@@ -797,11 +707,11 @@ static bool rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wav
                       a.moe_expert_ids, a.moe_slot_scale, (long long)a.moe_expert_stride, a.moe_x_div, a.moe_num_experts, NextHint()};
   dim3 grid(nwg), block(W * 64);
 #define RP_GO(TT)                                                                                                                     \
-  if constexpr ((PRO == 0 && EPI == 0) ? (TT <= 6 && rp_fits(W, MT, G, TT) && (MT == 1 || TT == 0 || TT == 4))                           \
-                : (MT == 2)            ? (PRO == 0 && W == 8 && NT && !(G & 1) && rp_fits(8, 2, G, TT))   /* SiLU-mul epilogue, 17..32 rows */ \
-                                       : (W == 16 ? (NT && MT == 1 && rp_fits_fused(G, TT, PRO, EPI))                                            \
-                                                 : (W == 8 && NT && MT == 1 && PRO == 0 && EPI == 1 && TT == 0 && G == 4))) { /* SiLU epilogue in rounds mode */ \
-    auto kern = gemv_repacked_kernel<G, TT, W, NT, MT, PRO, EPI>;                                                                       \
+  if constexpr ((EPI == 0) ? (TT <= 6 && rp_fits(W, MT, G, TT) && (MT == 1 || TT == 0 || TT == 4))                                          \
+                : (MT == 2) ? (W == 8 && NT && !(G & 1) && rp_fits(8, 2, G, TT))                /* SiLU-mul epilogue, 17..32 rows */            \
+                            : (W == 16 ? (NT && MT == 1 && rp_fits_fused(G, TT, EPI))                                                           \
+                                       : (W == 8 && NT && MT == 1 && EPI == 1 && TT == 0 && G == 4))) {  /* SiLU epilogue in rounds mode */       \
+    auto kern = gemv_repacked_kernel<G, TT, W, NT, MT, EPI>;                                                                       \
     if (lds > 64 * 1024) {                       /* one workgroup per CU: opt in to more of its 160 KiB of LDS, once per device */       \
       static unsigned long long opted[2] = {0ull, 0ull};                                                                                \
       if (!opt_in_dynamic_lds((const void*)kern, kRpMaxLds, opted)) return false;                                                        \
@@ -825,17 +735,17 @@ static bool rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wav
   return false;
 }
 
-template <int W, bool NT, int MT, int PRO = 0, int EPI = 0>
+template <int W, bool NT, int MT, int EPI = 0>
 static bool rp_launch_g(int G, const GemmArgs& a, const void* packed, int NG, int per_wave, int T, int nwg, size_t lds) {
   switch (G) {
-    case 1: return rp_launch<1, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds);
-    case 2: return rp_launch<2, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds);
-    case 3: return rp_launch<3, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds);
-    case 4: return rp_launch<4, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds);
-    case 5: return rp_launch<5, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds);
-    case 6: return rp_launch<6, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds);
-    case 7: return rp_launch<7, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds);
-    default: return rp_launch<8, W, NT, MT, PRO, EPI>(a, packed, NG, per_wave, T, nwg, lds);
+    case 1: return rp_launch<1, W, NT, MT, EPI>(a, packed, NG, per_wave, T, nwg, lds);
+    case 2: return rp_launch<2, W, NT, MT, EPI>(a, packed, NG, per_wave, T, nwg, lds);
+    case 3: return rp_launch<3, W, NT, MT, EPI>(a, packed, NG, per_wave, T, nwg, lds);
+    case 4: return rp_launch<4, W, NT, MT, EPI>(a, packed, NG, per_wave, T, nwg, lds);
+    case 5: return rp_launch<5, W, NT, MT, EPI>(a, packed, NG, per_wave, T, nwg, lds);
+    case 6: return rp_launch<6, W, NT, MT, EPI>(a, packed, NG, per_wave, T, nwg, lds);
+    case 7: return rp_launch<7, W, NT, MT, EPI>(a, packed, NG, per_wave, T, nwg, lds);
+    default: return rp_launch<8, W, NT, MT, EPI>(a, packed, NG, per_wave, T, nwg, lds);
   }
 }
 

@@ -256,7 +256,7 @@ int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed) {
   // Cost in rounds of the 256 CUs: ceil(tiles_A / 256) + 0.84 ceil(tiles_B / 256) (+ a little for the second launch); the
   // smallest wins, ties go to fewer launches / wider tiles.  2048 x 11008: 32 x 16 = 512 wide tiles (2 rounds) + 15 x 16 = 240
   // narrow ones (0.75) instead of 688 wide ones (3 rounds).  AWQ_PF_SPLIT=0 keeps the single launch (A/B).
-  static const bool env_split = !(getenv("AWQ_PF_SPLIT") && atoi(getenv("AWQ_PF_SPLIT")) == 0);
+  static const bool env_split = lab_env("AWQ_PF_SPLIT", 1) != 0;
   const int nby = (a.M + kPfBM - 1) / kPfBM, nA_max = (NG + 15) / 16;
   int best_nA = nA_max;
   double best = 1e30;
@@ -272,7 +272,7 @@ int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed) {
   // Few row tiles (M up to ~384 on a wide matrix): 128 x 128 tiles (NJ = 2) fill more CUs per round; a round of them measured
   // kNarrow2 of a round of wide ones.  Taken only when it beats the wide / 192-wide split.
   constexpr double kNarrow2 = 0.65;      // 43.5 us for 172 tiles against 73.5 for a round of wide ones (M = 256, 4096 x 11008)
-  static const int env_nj2 = getenv("AWQ_PF_NJ2") ? atoi(getenv("AWQ_PF_NJ2")) : -1;      // A/B: 0 never, 1 always
+  static const int env_nj2 = lab_env("AWQ_PF_NJ2", -1);      // lab knob: 0 never, 1 always
   const double cost2 = kNarrow2 * (double)((((NG + 7) / 8) * nby + 255) / 256);
   if (env_nj2 == 1 || (env_nj2 != 0 && env_split && cost2 < best - 1e-9)) return pf_launch_region<2>(a, qw_r, zs_r, NG, 0, NG);
   if (gA > 0) {

@@ -112,9 +112,9 @@ __global__ __launch_bounds__(kRpsWaves * 64, 2) void gemv_rps_kernel(const uint1
 
 // Strip width and slice count.  Narrow matrices only (the one-strip-per-CU kernels already have few, wide strips when N is large).
 bool rps_plan(const GemmArgs& a, int* G_out, int* S_out, int* kb_slice_out) {
-  static const int env_on = getenv("AWQ_RPS") ? atoi(getenv("AWQ_RPS")) : 1;
-  static const int env_g = getenv("AWQ_RPS_G") ? atoi(getenv("AWQ_RPS_G")) : 0, env_s = getenv("AWQ_RPS_S") ? atoi(getenv("AWQ_RPS_S")) : 0;
-  static const int env_minm = getenv("AWQ_RPS_MINM") ? atoi(getenv("AWQ_RPS_MINM")) : 0;
+  static const int env_on = lab_env("AWQ_RPS", 1);
+  static const int env_g = lab_env("AWQ_RPS_G", 0), env_s = lab_env("AWQ_RPS_S", 0);
+  static const int env_minm = lab_env("AWQ_RPS_MINM", 0);
   if (!env_on || !repacked_fast(a.K, a.N, a.g, a.dtype) || a.M > 32 || a.ldx % 8 || (((uintptr_t)a.x) & 15)) return false;
   const int NG = rp_groups(a.N), KB = a.K / 128;
   // measured (tools/kbench rgemm, us, one-strip kernels -> this one): 11008 x 4096 at 32 / 16 rows 23.2 -> 17.3 / 14.5 -> 11.5;

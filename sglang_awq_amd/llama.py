@@ -281,10 +281,6 @@ class GraphedDecoder:
         splits = 1
         if self.start_pos >= 384:
             splits = max(1, min(16, 256 // max(1, self.batch * layer.num_heads)))
-        import os
-
-        if os.environ.get("AWQ_ATTN_SPLITS"):                 # A/B knob
-            splits = int(os.environ["AWQ_ATTN_SPLITS"])
         for lyr in self.model.layers:
             lyr.attn_splits = splits
 

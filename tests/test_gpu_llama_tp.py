@@ -73,3 +73,34 @@ def test_tiny_llama_tp2_matches_tp1(tmp_path):
         assert int(heads) == 2 and int(kv) == 1
         # fp16 partial sums are rounded before the all-reduce: allow a few output ulps of the logit scale
         assert float(err) <= 2e-2 * float(scale) + 2e-2, f"rank {rank}: TP=2 logits off by {err} (scale {scale})"
+
+
+def _torchrun_bench_decode(extra_env, port):
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_TEST_BACKEND="gloo", BENCH_TEST_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench_decode.py"), "--model", "70b", "--layers", "2", "--batches", "1,8",
+           "--steps", "4", "--context", "64", "--cpu-seconds", "0"]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+
+
+def test_bench_decode_70b_two_ranks_rehearsal_and_failure_exit_code():
+    """BASELINE configs[4] kept from rotting without an 8-GPU node: `bench_decode.py --model 70b` under torchrun at world 2 (both
+    ranks on this GPU, gloo collectives, 2 of the 80 layers): per-rank shards of the 70B linears (KV heads split 8 -> 4 per rank),
+    row-parallel all-reduces, the JSON contract; and a rank that dies must end the job with a non-zero exit code
+    (reference: RowParallelLinear.forward + all-reduce, python/sglang/srt/layers/linear.py:1388-1414)."""
+    import json
+
+    port = 29700 + os.getpid() % 200
+    r = _torchrun_bench_decode({}, port)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    recs = [l for l in lines if "batch" in l]
+    assert [x["batch"] for x in recs] == [1, 8] and all(x["value"] > 0 and x["metric"].endswith("TP=2") for x in recs)
+    assert all(x["graph_replay"] is False and x["graph_capture_error"] for x in recs)      # gloo cannot be captured: said, not hidden
+    assert any("summary" in l for l in lines)
+    r = _torchrun_bench_decode({"BENCH_TEST_FAIL_RANK": "1"}, port + 1)
+    assert r.returncode != 0, "a failed rank must end the job with a non-zero exit code"

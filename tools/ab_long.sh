@@ -1,4 +1,6 @@
 #!/bin/bash
+# the knobs below are read by the laboratory build only: make -C sglang_awq_amd/csrc lab  (-DAWQ_LAB -> sglang_awq_amd/lib_ab)
+export LD_LIBRARY_PATH=sglang_awq_amd/lib_ab:$LD_LIBRARY_PATH
 # Deep / wide one-row shapes: the long straight-line form of gemv_rp2_kernel (up to 32 units per wave) against the round-1 loop kernel
 # (AWQ_RP2=0), tools/kbench rgemm, rotating weight sets (> 2 x the Infinity Cache), graph replay
 out=${1:-gpurun_out/ab_long.log}

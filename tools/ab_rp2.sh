@@ -1,4 +1,6 @@
 #!/bin/bash
+# the knobs below are read by the laboratory build only: make -C sglang_awq_amd/csrc lab  (-DAWQ_LAB -> sglang_awq_amd/lib_ab)
+export LD_LIBRARY_PATH=sglang_awq_amd/lib_ab:$LD_LIBRARY_PATH
 # A/B of the decode GEMV variants over the shapes of the 7B / 70B linears (tools/kbench rgemm; 16 rotating weight sets, graph replay)
 out=${1:-gpurun_out/ab_rp2.log}
 : > $out

@@ -1,4 +1,6 @@
 #!/bin/bash
+# the knobs below are read by the laboratory build only: make -C sglang_awq_amd/csrc lab  (-DAWQ_LAB -> sglang_awq_amd/lib_ab)
+export LD_LIBRARY_PATH=sglang_awq_amd/lib_ab:$LD_LIBRARY_PATH
 # A/B of the loop-form decode GEMV (gemv_rp3_kernel, AWQ_RP3=1) against the round-1 loop kernel (AWQ_RP3=0) with tools/kbench rgemm:
 # 16 rotating weight sets, graph replay.  KBENCH_WS=0: no split-K scratch, so 9..16 rows take the one-strip route on both sides.
 out=${1:-gpurun_out/ab_rp3.log}

@@ -1,4 +1,6 @@
 #!/bin/bash
+# the knobs below are read by the laboratory build only: make -C sglang_awq_amd/csrc lab  (-DAWQ_LAB -> sglang_awq_amd/lib_ab)
+export LD_LIBRARY_PATH=sglang_awq_amd/lib_ab:$LD_LIBRARY_PATH
 # A/B: does the 20-step figure depend on how long the GPU was busy right before the timed region?
 set -e
 mkdir -p gpurun_out

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Print VGPR / scratch use of every gemv_repacked_kernel<G, T, W, NT, MT, PRO, EPI> instantiation (hipcc resource remarks).
+"""Print VGPR / scratch use of every gemv_repacked_kernel<G, T, W, NT, MT, EPI> instantiation (hipcc resource remarks).
 
 The launch heuristic's `rp_fits` table in sglang_awq_amd/csrc/awq_repacked.hip is derived from this output;
 run it after touching the kernel.  Exit status 1 if any built instantiation uses scratch.
@@ -7,7 +7,7 @@ run it after touching the kernel.  Exit status 1 if any built instantiation uses
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRCS = [os.path.join(ROOT, "sglang_awq_amd", "csrc", f) for f in ("awq_repacked.hip", "awq_repacked_fused.hip", "awq_repacked_ext.hip",
+SRCS = [os.path.join(ROOT, "sglang_awq_amd", "csrc", f) for f in ("awq_repacked.hip", "awq_repacked_fused.hip", "awq_repacked_loop.hip", "awq_repacked_ext.hip",
                                                                    "awq_repacked_prefill.hip")]
 
 
@@ -21,10 +21,11 @@ def main():
     rows = []
     for blk in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
         name = blk.split()[0]
-        m = re.search(r"gemv_repacked_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)ELi(n?\d+)ELi(\d+)E", name)
+        m = re.search(r"gemv_repacked_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)ELi(\d+)E", name)
         if not m:
             continue
-        G, T, W, NT, MT, PRO, EPI = (int(v.replace("n", "-")) for v in m.groups())
+        G, T, W, NT, MT, EPI = (int(v) for v in m.groups())
+        PRO = 0
 
         def field(k):
             mm = re.search(k + r": (\d+)", blk)
