@@ -117,8 +117,11 @@ int awq_gemm_ex(const void* x, int64_t ldx, const int32_t* qweight, const void* 
  * streaming GEMV (linear weight stream, no cross-workgroup reduction, no workspace), for larger M an MFMA-bound
  * tiled kernel whose B fragments go from the copy straight to registers (an M <= 32 call whose reduction scratch
  * would not fit returns AWQ_ERR_BAD_VARIANT: use awq_gemm).
- * Supported: fp16, K % 128 == 0, group_size % 128 == 0; otherwise awq_repacked_bytes returns 0 and the other
- * two return AWQ_ERR_BAD_VARIANT (callers keep using awq_gemm).
+ * Supported: fp16 or bf16 (the dtype of the scales the copy is made from = the dtype of x and y), K % 128 == 0, group_size a
+ * multiple of 128 or one of 32 / 64 (the group sizes of the reference's Triton path, awq_triton.py:250); otherwise
+ * awq_repacked_bytes returns 0 and the other two return AWQ_ERR_BAD_VARIANT (callers keep using awq_gemm).  The hand-tuned kernels
+ * (straight-line / loop-form GEMV, hand-pipelined prefill tiles) exist for fp16 with group_size % 128 == 0; bf16 and the small
+ * groups run compiler-scheduled kernels on the same layout.
  */
 size_t awq_repacked_bytes(int64_t K, int64_t N, int64_t group_size, int dtype);
 
@@ -141,34 +144,6 @@ size_t awq_gemm_repacked_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_
 
 int awq_gemm_repacked_ws(const void* x, int64_t ldx, const void* packed, const void* bias, void* y, void* workspace,
                          size_t workspace_bytes, int64_t M, int64_t K, int64_t N, int64_t group_size, int dtype, void* stream);
-
-/*
- * Next-weights hint.  Decode runs a chain of weight-streaming kernels; weights do not depend on activations, so a kernel can ask
- * for the first bytes of the NEXT linear's weights once its own loads are out: the HBM channels then keep working through its
- * reduction / store tail and the launch boundary, and the next kernel finds those lines in the Infinity Cache.  Purely a
- * performance hint: results never depend on it, the touched bytes are read and discarded, and it must describe readable device
- * memory (`regions` pieces of `span` bytes, multiple of 64, `stride` bytes apart from `ptr`).  wave_min (0..15): only the
- * later waves of each workgroup touch.  awq_next_hint_for_gemm_repacked() fills the hint with what awq_gemm_repacked's decode
- * kernel reads first for a linear of the given shape (the leading column groups of every strip), about `budget_bytes` in all;
- * returns AWQ_ERR_BAD_VARIANT (and a hint with ptr == NULL) where no such kernel would run.  Kernels without a touch path ignore
- * the hint.  (The reference has no counterpart: its linears are separate dequantise + matmul launches, awq.py:434-451.)
- */
-typedef struct awq_next_hint {
-  const void* ptr;
-  int64_t stride;
-  int32_t span;
-  int32_t regions;
-  int32_t wave_min;
-  int32_t reserved;
-} awq_next_hint;
-
-int awq_next_hint_for_gemm_repacked(const void* packed, int64_t M, int64_t K, int64_t N, int64_t group_size, int dtype,
-                                    int64_t budget_bytes, awq_next_hint* out);
-
-/* awq_gemm_repacked_ws with a next-weights hint (next == NULL or next->ptr == NULL: exactly awq_gemm_repacked_ws). */
-int awq_gemm_repacked_next(const void* x, int64_t ldx, const void* packed, const void* bias, void* y, void* workspace,
-                           size_t workspace_bytes, int64_t M, int64_t K, int64_t N, int64_t group_size, int dtype,
-                           const awq_next_hint* next, void* stream);
 
 #ifdef __cplusplus
 }

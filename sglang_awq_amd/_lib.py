@@ -28,8 +28,6 @@ EXPORTS = (
     "awq_gemm_repacked",
     "awq_gemm_repacked_workspace_bytes",
     "awq_gemm_repacked_ws",
-    "awq_next_hint_for_gemm_repacked",
-    "awq_gemm_repacked_next",
 )
 # include/awq_aux.h (decode-harness helpers, not part of the operator boundary)
 AUX_EXPORTS = ("awq_aux_add_rmsnorm", "awq_aux_decode_attention", "awq_aux_decode_attention_workspace_bytes",
@@ -40,12 +38,6 @@ ABI_VERSION = 2
 DTYPE_F16, DTYPE_BF16, DTYPE_F32 = 0, 1, 2
 GEMM_AUTO, GEMM_GENERIC, GEMM_SKINNY, GEMM_TILED = 0, 1, 2, 3
 
-
-
-class NextHint(ctypes.Structure):
-    """include/awq_hip.h: awq_next_hint — the first bytes the next kernel on the stream will read (a performance hint)."""
-    _fields_ = [("ptr", ctypes.c_void_p), ("stride", ctypes.c_int64), ("span", ctypes.c_int32), ("regions", ctypes.c_int32),
-                ("wave_min", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 _lock = threading.Lock()
@@ -93,10 +85,6 @@ def _bind(L):
     L.awq_gemm_repacked_workspace_bytes.restype = ctypes.c_size_t
     L.awq_gemm_repacked_ws.argtypes = [vp, i64, vp, vp, vp, vp, ctypes.c_size_t, i64, i64, i64, i64, ci, vp]
     L.awq_gemm_repacked_ws.restype = ci
-    L.awq_next_hint_for_gemm_repacked.argtypes = [vp, i64, i64, i64, i64, ci, i64, ctypes.POINTER(NextHint)]
-    L.awq_next_hint_for_gemm_repacked.restype = ci
-    L.awq_gemm_repacked_next.argtypes = [vp, i64, vp, vp, vp, vp, ctypes.c_size_t, i64, i64, i64, i64, ci, ctypes.POINTER(NextHint), vp]
-    L.awq_gemm_repacked_next.restype = ci
     L.awq_aux_add_rmsnorm.argtypes = [vp, vp, vp, vp, i64, i64, ctypes.c_float, vp]
     L.awq_aux_add_rmsnorm.restype = ci
     L.awq_aux_decode_attention.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, ctypes.c_float, ci, vp, sz, vp]

@@ -204,31 +204,6 @@ int awq_gemm_repacked(const void* x, int64_t ldx, const void* packed, const void
 
 int awq_gemm_repacked_ws(const void* x, int64_t ldx, const void* packed, const void* bias, void* y, void* workspace,
                          size_t workspace_bytes, int64_t M, int64_t K, int64_t N, int64_t group_size, int dtype, void* stream) {
-  return awq_gemm_repacked_next(x, ldx, packed, bias, y, workspace, workspace_bytes, M, K, N, group_size, dtype, nullptr, stream);
-}
-
-int awq_next_hint_for_gemm_repacked(const void* packed, int64_t M, int64_t K, int64_t N, int64_t group_size, int dtype,
-                                    int64_t budget_bytes, awq_next_hint* out) {
-  if (!out) return AWQ_ERR_NULL_POINTER;
-  *out = awq_next_hint{nullptr, 0, 0, 0, 0, 0};
-  if (!packed) return AWQ_ERR_NULL_POINTER;
-  if (M < 1 || M > 16 || budget_bytes <= 0 || !repacked_fast(K, N, group_size, dtype)) return AWQ_ERR_BAD_VARIANT;
-  int G = 0, nwg = 0;
-  if (!gemv_strip_geometry(K, N, &G, &nwg)) return AWQ_ERR_BAD_VARIANT;
-  // a strip is G column groups of KB KiB each, streamed column group by column group (awq_repacked_gemv.h, RP2_CMAJOR): the first
-  // bytes every workgroup asks for are the leading column groups of its strip
-  const int64_t cg_bytes = (K / 128) * 1024, strip = (int64_t)G * cg_bytes;
-  int64_t span = (budget_bytes / nwg) & ~(int64_t)63;
-  if (span < 64) span = 64;
-  if (span > strip) span = strip;
-  if (span > (1 << 30)) return AWQ_ERR_BAD_VARIANT;
-  out->ptr = packed; out->stride = strip; out->span = (int32_t)span; out->regions = nwg; out->wave_min = 0;
-  return AWQ_OK;
-}
-
-int awq_gemm_repacked_next(const void* x, int64_t ldx, const void* packed, const void* bias, void* y, void* workspace,
-                           size_t workspace_bytes, int64_t M, int64_t K, int64_t N, int64_t group_size, int dtype,
-                           const awq_next_hint* next, void* stream) {
   if (!packed) return AWQ_ERR_NULL_POINTER;
   if (K <= 0 || N <= 0 || group_size <= 0 || N % 8 || K % group_size || M < 0 || ldx < K) return AWQ_ERR_BAD_SHAPE;
   if (M == 0) return AWQ_OK;
@@ -241,10 +216,6 @@ int awq_gemm_repacked_next(const void* x, int64_t ldx, const void* packed, const
   a.workspace = workspace; a.workspace_bytes = workspace ? workspace_bytes : 0;      // optional: only the split-K route for 9..32 rows uses it
   a.M = (int)M; a.K = (int)K; a.N = (int)N; a.g = (int)group_size; a.dtype = dtype; a.tune = 0;
   a.stream = (hipStream_t)stream;
-  if (next && next->ptr) {
-    a.next.ptr = (const unsigned char*)next->ptr; a.next.stride = next->stride; a.next.span = next->span; a.next.regions = next->regions;
-    a.next.wave_min = next->wave_min;
-  }
   return repacked_dispatch(a, packed);
 }
 

@@ -135,39 +135,4 @@ __device__ __forceinline__ void dequant_word(uint32_t w, uint32_t zw, const void
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// "Next weights" hint (include/awq_hip.h: awq_next_hint).  Weights do not depend on activations: a kernel that has issued the
-// last of its own weight loads can ask for the first bytes the NEXT kernel on the stream will want, so that the HBM channels
-// keep working through this kernel's reduction / store tail and the launch boundary, and the next kernel finds those lines in
-// the Infinity Cache (and, placement permitting, the XCD's L2).  One dword per 64-byte line is loaded and discarded.
-// Regions: `regions` pieces of `span` bytes (multiple of 64), `stride` bytes apart, from `ptr`.  A wave with slot number s of
-// nslots touches lines [(s * passes + k) * 64, +64), k < passes (passes in {1, 2}, chosen by the launcher so that the grid covers
-// the regions; lines past the end are skipped).  wave_min: only waves >= wave_min of a workgroup touch (the later waves of a
-// workgroup are the ones whose loads are served last).
-struct NextHint {
-  const unsigned char* ptr = nullptr;
-  long long stride = 0;
-  int span = 0, regions = 0, passes = 1, wave_min = 0;
-};
-
-// The loads are inline asm (hipcc must not wait for them anywhere: nothing consumes the data); k0 / k1 keep their destination
-// registers reserved until next_touch_wait(), which every touching wave runs last (a VGPR the compiler re-used before the data
-// landed would be overwritten under its feet).
-__device__ __forceinline__ void next_touch(const NextHint& h, int slot, int lane, uint32_t& k0, uint32_t& k1) {
-  const int lpr = h.span >> 6, total = h.regions * lpr;
-  int l = slot * h.passes * 64 + lane;
-  if (l < total) {
-    const int reg = l / lpr;
-    const unsigned char* p = h.ptr + (long long)reg * h.stride + (size_t)(l - reg * lpr) * 64;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(k0) : "v"(p) : "memory");
-  }
-  l += 64;
-  if (h.passes > 1 && l < total) {
-    const int reg = l / lpr;
-    const unsigned char* p = h.ptr + (long long)reg * h.stride + (size_t)(l - reg * lpr) * 64;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(k1) : "v"(p) : "memory");
-  }
-}
-__device__ __forceinline__ void next_touch_wait(uint32_t& k0, uint32_t& k1) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(k0), "+v"(k1) : : "memory"); }
-
 }  // namespace awq

@@ -48,8 +48,6 @@ struct GemmArgs {
   int moe_x_div = 1;                 // activation row of slot s = s / moe_x_div
   int moe_slots = 0;
   int moe_num_experts = 0;           // ids outside [0, moe_num_experts) are padded slots: zero output rows
-  // optional: bytes the next kernel on the stream will read first (awq_hip.h: awq_next_hint); ptr == nullptr = none
-  NextHint next;
 };
 
 int launch_dequantize(const int32_t* qweight, const void* scales, const int32_t* qzeros, void* out, int64_t K,

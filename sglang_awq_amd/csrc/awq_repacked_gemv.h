@@ -96,7 +96,6 @@ struct RpFuse {
   int x_div;
   int num_experts;             // ids outside [0, num_experts) mark padded slots (the reference writes -1 for the padded tokens of a
                                // graph batch, layers/moe/topk.py:705-712): their output row is zero-filled, no weight is read
-  NextHint next;               // bytes the next kernel on the stream reads first (gemv_rp2_kernel only; ptr == nullptr: none)
 };
 
 // T = k-blocks per wave when it is small enough to issue every load up front (straight-line code, exact
@@ -252,8 +251,8 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
 // The earlier norm prologue (round 1, inside gemv_repacked_kernel; removed) needed every workgroup to re-read all of h + delta and one
 // workgroup barrier before its weight loads: +1.6 us at M = 1, +6.5 at M = 8; this form costs two extra staging loads.
 #ifndef RP2_CMAJOR
-#define RP2_CMAJOR 1          // unit i = (c = i / T, t = i % T): a wave's consecutive loads are contiguous, and the first third of what a
-#endif                        // workgroup asks for is column group 0 of its strip (what a next-weights hint covers); 0: t-major (round 2)
+#define RP2_CMAJOR 1          // unit i = (c = i / T, t = i % T): a wave's consecutive loads are contiguous; 0: t-major (round 2; same speed,
+#endif                        // profiles/r03_kbench_next_hint_ab.txt)
 #ifndef RP2_EARLY
 #define RP2_EARLY 1           // 0: A/B build, the replacement load is issued behind the unit's compute (round-2 first form)
 #endif
@@ -379,23 +378,12 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
     const unsigned char* p = (const unsigned char*)(qw_r + ((size_t)(cg0 + c) * KB + kb) * 64) + loff;
     wbuf[i % RB] = __builtin_nontemporal_load((const u32x4_t*)p);      // streamed once: keep it out of the caches' way
   };
-  // next-weights hint: touched right behind this wave's LAST own weight load, so the CU's memory queue never runs dry between the
-  // end of this kernel's stream and the start of the next one's
-  uint32_t nk0 = 0, nk1 = 0;
-  const bool touches = fz.next.ptr != nullptr && wave >= fz.next.wave_min;       // wave-uniform
-  auto touch_next = [&]() {
-    if (touches) {
-      const int tw = W - fz.next.wave_min;
-      next_touch(fz.next, ((int)(blockIdx.y * gridDim.x + blockIdx.x)) * tw + (wave - fz.next.wave_min), lane, nk0, nk1);
-    }
-  };
 #pragma unroll
   for (int i = 0; i < DD; ++i) {
     load_w(i);
     if (D != 0 && i < 2) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
   }
   __builtin_amdgcn_sched_barrier(0);
-  if (DD >= L) { touch_next(); __builtin_amdgcn_sched_barrier(0); }
   if constexpr (NORM) {
 #pragma unroll
     for (int i = 0; i < CHS; ++i) {
@@ -462,7 +450,6 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
       asm volatile("" : "+v"(w));                        // unit i has arrived (the wait sits here) ...
       __builtin_amdgcn_sched_barrier(0);
       load_w(i + DD);                                    // ... its replacement leaves at once, into the spare register set
-      if (i + DD == L - 1) touch_next();
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -478,7 +465,6 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
     __builtin_amdgcn_sched_barrier(0);
     if (RB == DD && i + DD < L) {
       load_w(i + DD);
-      if (i + DD == L - 1) touch_next();
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -545,7 +531,6 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
       store_output<AWQ_DTYPE_F16>(y, (size_t)m * N + n, v, bias, n);
     }
   }
-  if (touches) next_touch_wait(nk0, nk1);
 }
 
 // rp2 exists for T <= 8, G <= 8, G T <= 16 (unrolled length), staging of <= 8 chunks per lane; returns false when the
@@ -571,16 +556,8 @@ static bool rp2_launch_t(const GemmArgs& a, const void* packed, int NG, int chun
     int lg = 0;
     while ((1 << lg) < gk) ++lg;
     const int gshift = 12 + lg, gmul = (int)(((1ll << gshift) + gk - 1) / gk);
-    NextHint nh = a.next;                                 // sized to this launch's grid: one or two lines of 64 B per touching lane
-    if (nh.ptr != nullptr) {
-      if (nh.wave_min < 0 || nh.wave_min > 15 || nh.span <= 0 || (nh.span & 63) || nh.regions <= 0) nh = NextHint();
-      else {
-        const long long slots = (long long)nwg * (a.moe_slots > 0 ? a.moe_slots : 1) * (16 - nh.wave_min);
-        nh.passes = (long long)nh.regions * (nh.span >> 6) > slots * 64 ? 2 : 1;
-      }
-    }
     const RpFuse fz = {(const half_t*)a.norm_h, (const half_t*)a.norm_delta, (const half_t*)a.norm_w, (half_t*)a.norm_h_out, a.norm_eps,
-                      a.moe_expert_ids, a.moe_slot_scale, (long long)a.moe_expert_stride, a.moe_x_div, a.moe_num_experts, nh};
+                      a.moe_expert_ids, a.moe_slot_scale, (long long)a.moe_expert_stride, a.moe_x_div, a.moe_num_experts};
 #define RP2_GO(CHS, DEP, ONE, NRM)                                                                                                 \
     do {                                                                                                                           \
       auto kern = gemv_rp2_kernel<G, T, CHS, DEP, EPI, ONE, NRM>;                                                                  \
@@ -704,7 +681,7 @@ static bool rp_launch(const GemmArgs& a, const void* packed, int NG, int per_wav
   const u32x4_t* qw_r = (const u32x4_t*)packed;
   const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
   const RpFuse fz = {(const half_t*)a.norm_h, (const half_t*)a.norm_delta, (const half_t*)a.norm_w, (half_t*)a.norm_h_out, a.norm_eps,
-                      a.moe_expert_ids, a.moe_slot_scale, (long long)a.moe_expert_stride, a.moe_x_div, a.moe_num_experts, NextHint()};
+                      a.moe_expert_ids, a.moe_slot_scale, (long long)a.moe_expert_stride, a.moe_x_div, a.moe_num_experts};
   dim3 grid(nwg), block(W * 64);
 #define RP_GO(TT)                                                                                                                     \
   if constexpr ((EPI == 0) ? (TT <= 6 && rp_fits(W, MT, G, TT) && (MT == 1 || TT == 0 || TT == 4))                                          \

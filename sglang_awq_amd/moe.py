@@ -61,7 +61,10 @@ class StandardCombineInput(NamedTuple):
 class AWQMoEMethod:
     """create_weights / process_weights_after_loading / create_moe_runner / apply for a layer of AWQ-quantised experts."""
 
-    MOE_SLOT_MAX_PAIRS = 8           # (token, expert) pairs served one grid row each; beyond: expert-sorted 16-row blocks
+    # (token, expert) pairs served one grid row each; beyond: expert-sorted 16-row blocks.  Measured on Mixtral-8x7B-like experts
+    # (E = 8, K = 4096, I = 14336, top-2; profiles/r03_time_moe.txt): a pair costs ~17.7 us on the slot route, the block route ~390 us
+    # for up to 16 rows per expert (+ the device-side alignment): they cross near 22 pairs
+    MOE_SLOT_MAX_PAIRS = 24
     MOE_GEMV_MAX_SLOTS = MOE_SLOT_MAX_PAIRS   # (name of rounds 1-2)
 
     def __init__(self, quant_config: AWQConfig):

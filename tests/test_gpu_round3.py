@@ -1,5 +1,5 @@
 """Round-3 parity additions (-m gpu): the long straight-line and loop forms of the decode GEMV (gemv_rp2_kernel up to 32 units per
-wave, gemv_rp3_kernel) against the oracle, the next-weights hint (results must not depend on it), AWQ-MoE behind the reference's call
+wave, gemv_rp3_kernel) against the oracle, AWQ-MoE behind the reference's call
 interface with padded ids, weight updates through `param.data.copy_` followed by the hook, scratch buffers under graph capture,
 bias loading through apply, outlier activations through the norm-folded GEMV."""
 import ctypes
@@ -54,33 +54,6 @@ def test_loop_form_gemv_vs_oracle(ops, K, N):
         if M in (1, 9):
             b = to_torch(synth.make_bias(N, "f16", 5), DEV)
             assert torch.equal(ops.awq_gemm_repacked(to_torch(x, DEV), packed, K, N, 128, b), y + b)
-
-
-def test_next_weights_hint_changes_nothing(ops):
-    """awq_gemm_repacked_next: the hint only touches (reads and discards) bytes of another buffer; y is bit-identical with and
-    without it, for every wave_min, whatever the hinted shape."""
-    lib = _lib.load()
-    K, N = 4096, 11008
-    w = [synth.make_awq_weights(K, N, 128, "f16", "A", seed=s) for s in (1, 2)]
-    packed = [ops.awq_repack(*_dev(*t)) for t in w]
-    for M in (1, 4, 16):
-        x = to_torch(synth.make_activations(M, K, "f16", "A", seed=M), DEV)
-        y0 = ops.awq_gemm_repacked(x, packed[0], K, N, 128)
-        for budget, wmin in ((1 << 20, 0), (6 << 20, 8), (64 << 20, 12)):
-            hint = _lib.NextHint()
-            rc = lib.awq_next_hint_for_gemm_repacked(ctypes.c_void_p(packed[1].data_ptr()), 1, K, N, 128, _lib.DTYPE_F16, budget, ctypes.byref(hint))
-            assert rc == 0 and hint.ptr == packed[1].data_ptr() and hint.span % 64 == 0
-            assert hint.stride * (hint.regions - 1) + hint.span <= packed[1].numel()          # inside the buffer
-            hint.wave_min = wmin
-            y = torch.empty_like(y0)
-            rc = lib.awq_gemm_repacked_next(ctypes.c_void_p(x.data_ptr()), K, ctypes.c_void_p(packed[0].data_ptr()), None,
-                                            ctypes.c_void_p(y.data_ptr()), None, 0, M, K, N, 128, _lib.DTYPE_F16, ctypes.byref(hint),
-                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-            assert rc == 0
-            assert torch.equal(y, y0), f"hint changed the result (M={M}, budget={budget}, wave_min={wmin})"
-    hint = _lib.NextHint()
-    assert lib.awq_next_hint_for_gemm_repacked(ctypes.c_void_p(packed[1].data_ptr()), 1, K, N, 64, _lib.DTYPE_F16, 1 << 20, ctypes.byref(hint)) == _lib.ERR_BAD_VARIANT
-    assert hint.ptr is None
 
 
 def _moe_layer(E, K, I, g, seed0=100):

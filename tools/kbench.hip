@@ -323,25 +323,7 @@ static int cmd_rgemm(int argc, char** argv) {
   void* ws = nullptr;
   const size_t ws_bytes = (getenv("KBENCH_WS") && atoi(getenv("KBENCH_WS")) == 0) ? 0 : awq_gemm_repacked_workspace_bytes(M, K, N, g, AWQ_DTYPE_F16);
   if (ws_bytes) { CK(hipMalloc(&ws, ws_bytes)); CK(hipMemset(ws, 0, ws_bytes)); }
-  // next-weights hint (awq_hip.h): KBENCH_NEXT = budget in KiB of the next set's weights to touch (0 = off), KBENCH_NEXT_WMIN = first touching wave
-  const long long next_kib = getenv("KBENCH_NEXT") ? atoll(getenv("KBENCH_NEXT")) : 0;
-  const int next_wmin = getenv("KBENCH_NEXT_WMIN") ? atoi(getenv("KBENCH_NEXT_WMIN")) : 0;
-  std::vector<awq_next_hint> hints(sets);
-  for (int i = 0; i < sets; ++i) {
-    hints[i] = awq_next_hint{nullptr, 0, 0, 0, 0, 0};
-    if (next_kib > 0) {
-      int rc = awq_next_hint_for_gemm_repacked(packed[(i + 1) % sets], M, K, N, g, AWQ_DTYPE_F16, next_kib * 1024, &hints[i]);
-      if (rc) { fprintf(stderr, "awq_next_hint_for_gemm_repacked: %s\n", awq_hip_status_string(rc)); return 1; }
-      hints[i].wave_min = next_wmin;
-    }
-  }
-  if (next_kib > 0) printf("next hint: stride %lld span %d regions %d wave_min %d\n", (long long)hints[0].stride, hints[0].span, hints[0].regions, hints[0].wave_min);
   auto launch = [&](int i) {
-    if (!fuse && next_kib > 0) {
-      int rc = awq_gemm_repacked_next(x, K, packed[i % sets], nullptr, y, ws, ws_bytes, M, K, N, g, AWQ_DTYPE_F16, &hints[i % sets], st);
-      if (rc) { fprintf(stderr, "awq_gemm_repacked_next: %s\n", awq_hip_status_string(rc)); exit(1); }
-      return;
-    }
     int rc = fuse ? awq_aux_gemv_repacked_fused(x, K, packed[i % sets], y, M, K, N, g, AWQ_DTYPE_F16, (fuse & 1) ? x : nullptr, delta, nw, hout,
                                                 1e-5f, (fuse & 2) ? 1 : 0, st)
                   : awq_gemm_repacked_ws(x, K, packed[i % sets], nullptr, y, ws, ws_bytes, M, K, N, g, AWQ_DTYPE_F16, st);

@@ -19,7 +19,7 @@ for n, p in layer.named_parameters():
         p.data.copy_((0.005 + 0.015 * torch.rand(p.shape, device=dev, generator=gen)).half())
 m.process_weights_after_loading(layer)
 wbytes = (layer.w13_packed.shape[1] + layer.w2_packed.shape[1])
-for T in (1, 2, 4, 8, 16):
+for T in (1, 2, 4, 8, 16, 64, 256):
     x = torch.randn(T, K, device=dev, generator=gen).half() * 0.5
     tw, ti = select_experts(torch.randn(T, E, device=dev, generator=gen), top_k)
     m.apply(layer, x, tw, ti); torch.cuda.synchronize()
@@ -34,4 +34,7 @@ for T in (1, 2, 4, 8, 16):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 50
     slots = T * top_k
-    print(f"T={T:2d} slots={slots:2d}: {us:8.1f} us per MoE layer  ({slots * wbytes / us / 1e3:7.1f} GB/s of expert weights streamed per slot)", flush=True)
+    route = "one grid row per pair" if slots <= AWQMoEMethod.MOE_SLOT_MAX_PAIRS else "expert-sorted 16-row blocks"
+    active = len(set(ti.view(-1).tolist()))
+    print(f"T={T:3d} pairs={slots:3d} ({route}, {active} active experts): {us:8.1f} us per MoE layer  ({active * wbytes / us / 1e3:7.1f} GB/s if every "
+          f"active expert were streamed once)", flush=True)
