@@ -16,6 +16,7 @@ DEV = "cuda:0"
 
 
 def run(cases: int, seed: int, verbose: bool = True) -> int:
+    ops.awq_gemm_cache_enable(True)                        # the op's repacked-copy cache is opt-in; this sweep owns its weights
     rng = np.random.default_rng(seed)
     Ms = [1, 2, 3, 5, 8, 9, 13, 16, 17, 24, 31, 32, 33, 48, 64, 97, 130, 160, 161, 200, 256, 257, 300, 385, 520]
     done = 0
@@ -27,6 +28,13 @@ def run(cases: int, seed: int, verbose: bool = True) -> int:
             kb = int(rng.choice([64, 72, 86]))             # deep matrices: the split-K GEMV's domain
         K = 128 * kb
         N = 8 * int(rng.integers(2, 40 if deep else 700)) # N % 8 == 0, ragged against 16 / 64 / 128 / 192 / 256
+        long_ = (not deep) and rng.random() < 0.12         # round 3: the long straight-line GEMV (17 .. 32 units per wave) and the loop form
+        if long_:
+            M = int(rng.choice([1, 1, 13, 16]))
+            if rng.random() < 0.5:
+                K, N = 128 * int(rng.choice([144, 160, 224, 256])), 8 * int(rng.integers(2, 64))           # 9 .. 16 k-blocks per wave
+            else:
+                K, N = 128 * int(rng.choice([48, 64])), 8 * int(rng.integers(2560, 3584))                    # strips of 5 .. 7 column groups
         divs = [d for d in (32, 64, 128, 256, 384, 512, K) if K % d == 0 and d <= K]
         g = int(rng.choice(divs))
         dt = "bf16" if rng.random() < 0.2 else "f16"
@@ -55,6 +63,8 @@ def run(cases: int, seed: int, verbose: bool = True) -> int:
             y3 = ops.awq_gemm_repacked(xw[:, 8:8 + K], packed, K, N, g)
             assert torch.equal(y3, y2), what + " (strided x differs)"
         done += 1
+        if it % 16 == 15:
+            ops.awq_gemm_cache_clear()
         if verbose and it % 10 == 0:
             print(f"{it:4d} ok  {what}", flush=True)
     return done
