@@ -734,6 +734,40 @@ static int cmd_stamps(int argc, char** argv) {
     if (!a2.empty()) printf(" w%d %.2f/%.2f", w, a2[a2.size() / 2], a4[a4.size() / 2]);
   }
   printf("\n");
+  // per workgroup: when its barrier fell (slot 5 of wave 0) and when it started; by blockIdx % 8 (blocks b and b + 8 share an XCD)
+  {
+    std::vector<std::pair<double, int>> fin;
+    std::vector<double> byx[8];
+    for (int b2 = 0; b2 < nwg; ++b2) {
+      const size_t i = ((size_t)b2 * v->W) * 8;
+      if (!h[i + 5]) continue;
+      const double t = (double)(h[i + 5] - t0) * 0.01;
+      fin.push_back({t, b2});
+      byx[b2 & 7].push_back(t);
+    }
+    std::sort(fin.begin(), fin.end());
+    if (!fin.empty()) {
+      printf("  workgroup barrier times: min %.2f p10 %.2f p50 %.2f p90 %.2f max %.2f\n", fin.front().first, fin[fin.size() / 10].first, fin[fin.size() / 2].first,
+             fin[fin.size() * 9 / 10].first, fin.back().first);
+      printf("  by blockIdx %% 8 (median / max):");
+      for (int x = 0; x < 8; ++x) { std::sort(byx[x].begin(), byx[x].end()); if (!byx[x].empty()) printf(" %d: %.2f/%.2f", x, byx[x][byx[x].size() / 2], byx[x].back()); }
+      printf("\n  slowest workgroups (block: barrier, start of wave 0, first data of wave 0, last wave's all-computed):");
+      for (size_t k = fin.size() > 12 ? fin.size() - 12 : 0; k < fin.size(); ++k) {
+        const int b2 = fin[k].second;
+        const size_t i = ((size_t)b2 * v->W) * 8;
+        double last = 0;
+        for (int w = 0; w < v->W; ++w) { const unsigned long long t = h[i + (size_t)w * 8 + 4]; if (t) last = std::max(last, (double)(t - t0) * 0.01); }
+        printf(" [%d: %.2f %.2f %.2f %.2f]", b2, fin[k].first, (double)(h[i] - t0) * 0.01, h[i + 2] ? (double)(h[i + 2] - t0) * 0.01 : -1.0, last);
+      }
+      printf("\n  fastest:");
+      for (size_t k = 0; k < 6 && k < fin.size(); ++k) {
+        const int b2 = fin[k].second;
+        const size_t i = ((size_t)b2 * v->W) * 8;
+        printf(" [%d: %.2f %.2f %.2f]", b2, fin[k].first, (double)(h[i] - t0) * 0.01, h[i + 2] ? (double)(h[i + 2] - t0) * 0.01 : -1.0);
+      }
+      printf("\n");
+    }
+  }
   // one workgroup in full
   const int b = nwg / 2;
   printf("  workgroup %d, per wave: start issued first half all barrier stored\n", b);
