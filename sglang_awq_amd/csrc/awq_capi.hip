@@ -25,7 +25,7 @@ bool pow2_le32(int v) { return v >= 1 && v <= 32 && (v & (v - 1)) == 0; }
 }  // namespace
 
 // Kernel choice on the fragment-major layout, shared by awq_gemm_repacked and the op's on-the-fly re-layout (so the two
-// routes give bit-identical results).
+// routes give bit-identical results).  The table of routes and the measurements behind every threshold: awq_dispatch.h.
 static int repacked_dispatch(const GemmArgs& a, const void* packed) {
   const int64_t M = a.M;
   // <= 32 rows: the streaming GEMV.  Up to 160 rows, passes of it (32 rows each) beat the 128 x 256 MFMA tiles, which
@@ -33,8 +33,8 @@ static int repacked_dispatch(const GemmArgs& a, const void* packed) {
   // wide tiles are few (narrow matrices, up to 512 rows) 128 x 64 tiles with the K split inside the workgroup fill the
   // chip better (11008 x 4096 at M = 256: 142 -> 90 us); beyond that the hand-pipelined wide tiles.
   static const int env_mid = lab_env("AWQ_MID", 1);      // lab knob: 0 = never the 128 x 64 tiles
-  if (M <= 32) {
-    if (M > 8 && a.workspace != nullptr) {             // narrow matrix, many rows: wide strips with K split across workgroups
+  if (M <= route::kGemvMaxRows) {
+    if (M >= route::kSplitKMinRows && a.workspace != nullptr) {             // narrow matrix, many rows: wide strips with K split across workgroups
       const int rs = launch_gemv_repacked_splitk(a, packed);
       if (rs != AWQ_ERR_BAD_VARIANT) return rs;
     }
@@ -53,12 +53,12 @@ static int repacked_dispatch(const GemmArgs& a, const void* packed) {
   if (!repacked_fast(a.K, a.N, a.g, a.dtype)) return launch_gemm_repacked_tiled(a, packed);   // bf16 / g in {32, 64}: the generic tiles from 33 rows on
   const bool aligned = a.ldx % 8 == 0 && (((uintptr_t)a.x) & 15) == 0;
   const int64_t wide_tiles = ((M + 127) / 128) * ((a.N + 255) / 256);
-  if (env_mid != 0 && aligned && M > 96 && wide_tiles <= 64 && repacked_fast(a.K, a.N, a.g, a.dtype)) return launch_gemm_repacked_ksplit(a, packed);
-  if (M <= 160) {
+  if (env_mid != 0 && aligned && M >= route::kKsplitMinRows && wide_tiles <= route::kKsplitMaxWideTiles && repacked_fast(a.K, a.N, a.g, a.dtype)) return launch_gemm_repacked_ksplit(a, packed);
+  if (M <= route::kGemvPassesMaxRows) {
     const size_t eb2 = 2;
-    for (int64_t m0 = 0; m0 < M; m0 += 32) {
+    for (int64_t m0 = 0; m0 < M; m0 += route::kGemvPassRows) {
       GemmArgs c = a;
-      c.M = (int)(M - m0 < 32 ? M - m0 : 32);
+      c.M = (int)(M - m0 < route::kGemvPassRows ? M - m0 : route::kGemvPassRows);
       c.x = (const char*)a.x + (size_t)m0 * a.ldx * eb2;
       c.y = (char*)a.y + (size_t)m0 * a.N * eb2;
       const int rc = launch_gemv_repacked(c, packed);
@@ -105,7 +105,7 @@ int awq_dequantize(const int32_t* qweight, const void* scales, const int32_t* qz
 // workspace (awq_repack, ~17 us at 4096 x 11008) buys the kernels of the fragment-major layout.  Measured against the
 // checkpoint-layout kernels (11008 x 4096: M = 64 212 -> 63 us, M = 256 217 -> 118, M = 2048 311 -> 225; 4096 x 11008:
 // M = 128 85 -> 61, M = 512 104 -> 89) it wins from the first row count the split-K decode kernel does not cover.
-constexpr int64_t kRepackOnTheFlyMinM = 33;
+constexpr int64_t kRepackOnTheFlyMinM = route::kRepackOnTheFlyMinM;
 constexpr size_t kWorkspaceHead = 4096;        // arrival counters of the split-K kernel live here
 
 size_t awq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t group_size, int dtype) {

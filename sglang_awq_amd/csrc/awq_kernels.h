@@ -8,6 +8,7 @@
 
 #include "../../include/awq_hip.h"
 #include "awq_device.h"
+#include "awq_dispatch.h"
 
 namespace awq {
 

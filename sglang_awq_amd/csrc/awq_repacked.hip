@@ -179,7 +179,7 @@ bool gemv_strip_geometry(int64_t K, int64_t N, int* G, int* nwg) {
   (void)K;
   const int NG = rp_groups(N);
   int g = (NG + 255) / 256;
-  if (g > kRpMaxG) return false;
+  if (g > route::kOneStripMaxGroups) return false;
   if (g > NG) g = NG;
   *G = g;
   *nwg = (NG + g - 1) / g;
@@ -211,7 +211,7 @@ int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
   // the other's stream (145 -> 51 us at 8192 x 57344, 4.8 TB/s).
   int G = (NG + 255) / 256;
   bool rounds = false;
-  if (G > kRpMaxG) { G = 3; rounds = true; }                       // measured 51 (G = 3) / 53 (2) / 54.5 (4) / 60 (1) us
+  if (G > route::kOneStripMaxGroups) { G = route::kRoundsGroups; rounds = true; }                       // measured 51 (G = 3) / 53 (2) / 54.5 (4) / 60 (1) us
   // (32 rows on wide strips: the reduction scratch, 8 waves x 32 x 16 G floats, goes past 64 KiB — that variant runs one
   // workgroup per CU anyway (190+ registers) and opts in to more of the CU's LDS; narrow rounds would need two resident)
   if (env_g >= 1 && env_g <= kRpMaxG) { G = env_g; rounds = (NG + G - 1) / G > 256; }
@@ -220,7 +220,7 @@ int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
   // 16 waves + non-temporal weight loads for matrices that are streamed from HBM (measured 7.2 vs 8.3 us at
   // 4096 x 11008); small ones (< 12 MB packed, largely L2 / Infinity-Cache resident) run better with 8 waves and
   // default-policy loads (4.2 vs 4.7 us at 4096 x 4096).
-  const bool big = (size_t)a.K * a.N / 2 >= (12u << 20);
+  const bool big = (size_t)a.K * a.N / 2 >= route::kStreamedMinBytes;
   const bool nt = env_nt >= 0 ? env_nt != 0 : big;
   int W = env_waves == 16 || env_waves == 8 ? env_waves : (big && !rounds ? 16 : 8);
   if (two_tiles || (size_t)W * a.M * 16 * G * sizeof(float) > 64 * 1024) W = 8;
@@ -241,7 +241,7 @@ int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
   // It also wins on small, largely cache-resident matrices as long as every one of the 16 waves has a k-block (KB >= 16):
   // 4096 x 4096 4.39 -> 4.07 us, 8192 x 1280 5.88 -> 4.72; with fewer k-blocks (1024 x 8192: 3.60 vs 3.81) the 8-wave form stays.
   static const int env_rp2 = rp_env("AWQ_RP2", 1), env_d = rp_env("AWQ_RP2_D", -1);
-  const bool rp2_small = !big && !rounds && env_waves == 0 && env_nt < 0 && KB >= 16;
+  const bool rp2_small = !big && !rounds && env_waves == 0 && env_nt < 0 && KB >= route::kRp2MinKBlocks;
   if (env_rp2 && !two_tiles && env_t != 0 && ((W == 16 && nt) || rp2_small)) {
     const int depth = env_d >= 0 ? env_d : 2;
     if (rp2_launch<0>(G, (KB + 15) / 16, a, packed, NG, depth, nwg)) return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
@@ -252,7 +252,7 @@ int launch_gemv_repacked(const GemmArgs& a, const void* packed) {
   static const int env_rp3 = rp_env("AWQ_RP3", 1);
   // measured (profiles/r03_kbench_rp3_ab.txt): faster than the round-1 loop kernel at 13..16 rows on narrow strips (11008 x 4096 at 16
   // rows 14.4 -> 13.1 us, 8192 x 1280 10.4 -> 8.5), slower below and on wide strips (register pressure: G >= 4 spills at 16 waves)
-  if (env_rp3 && !two_tiles && !rounds && KB >= 16 && env_t != 0 && env_waves == 0 && env_g == 0 && a.M >= 13 && G <= 2) {
+  if (env_rp3 && !two_tiles && !rounds && KB >= route::kRp2MinKBlocks && env_t != 0 && env_waves == 0 && env_g == 0 && a.M >= route::kRp3MinRows && G <= route::kRp3MaxGroups) {
     const int rc = launch_gemv_repacked_loop(a, packed);
     if (rc != AWQ_ERR_BAD_VARIANT) return rc;
   }

@@ -265,13 +265,13 @@ int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed) {
     const int nB = (rest + 11) / 12;
     if (nA == 0 && nB == 0) continue;
     // a round of narrow tiles measured 0.84 of a round of wide ones (62 vs 73.5 us at K = 4096: the x-tile staging does not shrink)
-    const double cost = (double)((nA * nby + 255) / 256) + 0.84 * (double)((nB * nby + 255) / 256) + (nA > 0 && nB > 0 ? 0.02 : 0.0);
+    const double cost = (double)((nA * nby + 255) / 256) + route::kNarrowRound192 * (double)((nB * nby + 255) / 256) + (nA > 0 && nB > 0 ? route::kSecondLaunch : 0.0);
     if (cost < best - 1e-9) { best = cost; best_nA = nA; }
   }
   const int gA = best_nA * 16 < NG ? best_nA * 16 : NG;
   // Few row tiles (M up to ~384 on a wide matrix): 128 x 128 tiles (NJ = 2) fill more CUs per round; a round of them measured
   // kNarrow2 of a round of wide ones.  Taken only when it beats the wide / 192-wide split.
-  constexpr double kNarrow2 = 0.65;      // 43.5 us for 172 tiles against 73.5 for a round of wide ones (M = 256, 4096 x 11008)
+  constexpr double kNarrow2 = route::kNarrowRound128;      // 43.5 us for 172 tiles against 73.5 for a round of wide ones (M = 256, 4096 x 11008)
   static const int env_nj2 = lab_env("AWQ_PF_NJ2", -1);      // lab knob: 0 never, 1 always
   const double cost2 = kNarrow2 * (double)((((NG + 7) / 8) * nby + 255) / 256);
   if (env_nj2 == 1 || (env_nj2 != 0 && env_split && cost2 < best - 1e-9)) return pf_launch_region<2>(a, qw_r, zs_r, NG, 0, NG);

@@ -121,9 +121,9 @@ bool rps_plan(const GemmArgs& a, int* G_out, int* S_out, int* kb_slice_out) {
   // 4096 x 4096 at 32 rows 10.6 -> 9.9, at 16 rows 6.7 -> 7.3 (not taken); more than two slices or four-group strips lose again
   // (also measured: 8192 x 1280 at 16 / 32 rows 10.4 -> 8.2 / 17.4 -> 14.1; no gain or a loss at K = 4096 (4096 x 4096, 4096 x 2560),
   // at N = 8192 (512 workgroups: two rounds) and with 3584 x 8192 — profiles/r02_kbench_splitk_ab.txt): deep and narrow only
-  const int minm = env_minm ? env_minm : 9;
-  if (a.M < minm || NG < 8 || (!env_minm && (KB < 64 || NG > 256))) return false;
-  const int G = env_g ? env_g : 2;
+  const int minm = env_minm ? env_minm : route::kSplitKMinRows;
+  if (a.M < minm || NG < 8 || (!env_minm && (KB < route::kRpsMinKBlocks || NG > route::kRpsMaxGroups))) return false;
+  const int G = env_g ? env_g : route::kRpsStripGroups;
   if (G != 2 && G != 4) return false;
   const int strips = (NG + G - 1) / G;
   // two slices once the strips alone fill half the chip; more only for very narrow matrices (at least one k-block per wave and slice)
