@@ -68,6 +68,13 @@ int awq_aux_moe_gemv(const void* x, int64_t ldx, int x_div, const void* packed_e
  * the repacked weight of expert block_expert[b] (< 0: unused block, skipped) and writes output row p of y [pairs, N] (or
  * [pairs, N / 2] with silu_mul); slot_scale[p] as in awq_aux_moe_gemv.  One launch streams each active expert once per 16 of its
  * rows.  fp16, group_size % 128 == 0; AWQ_ERR_BAD_VARIANT otherwise. */
+/* The alignment step itself on the device, one small launch: ids [pairs] int32 -> row_map [16 num_blocks] (pair indices grouped by
+ * expert, each expert's run padded with -1 to a multiple of 16) and block_expert [num_blocks] (-1 = unused block), num_blocks >=
+ * ceil(pairs / 16) + num_experts (the static bound).  Ids outside [0, num_experts) are dropped.  The order of the rows inside an expert's run
+ * is not specified (the outputs of awq_aux_moe_gemv_blocks do not depend on it).  num_experts <= 1024; AWQ_ERR_BAD_VARIANT beyond. */
+int awq_aux_moe_align_blocks(const int32_t* ids, int64_t pairs, int64_t num_experts, int32_t* row_map, int32_t* block_expert,
+                             int64_t num_blocks, void* stream);
+
 int awq_aux_moe_gemv_blocks(const void* x, int64_t ldx, int x_div, const void* packed_experts, int64_t expert_stride_bytes,
                             const int32_t* row_map, const int32_t* block_expert, int64_t num_blocks, const float* slot_scale,
                             void* y, int64_t K, int64_t N, int64_t group_size, int dtype, int silu_mul, void* stream);

@@ -22,7 +22,7 @@
 //                                                          for whole rounds + 128 x 192 for the rest,      split; 192 / 256 rows 51.5 -> 43 with 128 x 128 tiles
 //                                                          or 128 x 128 when few row tiles                 (r02_kbench_prefill_split_ab.txt, …_nj2_ab.txt)
 //  the torch op  M >= 33 without a cached copy             awq_repack into the workspace, then the above   11008 x 4096: M = 64 212 -> 63, M = 256 217 -> 118
-//  AWQ-MoE       <= 24 (token, expert) pairs               gemv_rp2_kernel, one grid row per pair          17.7 per pair (E = 8, 4096 / 14336); blocks 390+: cross at ~22
+//  AWQ-MoE       <= 12 (token, expert) pairs               gemv_rp2_kernel, one grid row per pair          ~17 per pair (E = 8, 4096 / 14336); blocks ~215: cross at ~13
 //                more                                      gemv_rp3_kernel on expert-sorted 16-row blocks  (r03_time_moe.txt; threshold in sglang_awq_amd/moe.py)
 #pragma once
 

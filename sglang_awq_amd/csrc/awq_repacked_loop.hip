@@ -41,6 +41,7 @@ __global__ __launch_bounds__(1024) void gemv_rp3_kernel(const uint16_t* __restri
                                                         void* __restrict__ y, int M, int K, int N, int groups, int gmul, int gshift,
                                                         int NG, int T, Rp3Moe moe) {
   constexpr int W = 16, L = G * TS, DD = 2, RB = 3;
+  constexpr bool XJIT = !M1 && G * 4 + CHS * 4 >= 28;     // wide strips with many staging chunks: x fragments just in time (registers)
   static_assert(L >= 1 && L <= 16, "a stage is 1..16 units");
   constexpr int XS = TS * 128 + 8;                       // halves per staged x row (+8: rows 16 B apart in bank phase)
   extern __shared__ __attribute__((aligned(16))) float red[];
@@ -73,34 +74,36 @@ __global__ __launch_bounds__(1024) void gemv_rp3_kernel(const uint16_t* __restri
   constexpr int NZ = G * TS * 4;
   static_assert(NZ <= 64, "zs words of a stage fit one load");
   const int nx = M * TS * 16;
+  // Register diet (16 waves x 128 registers): per-lane chunk coordinates are recomputed from the lane id where they are used (behind an
+  // opaque copy, or hipcc hoists them out of the stage loop and keeps 2-3 registers per chunk live across it); row offsets are 32-bit.
   u32x4_t sv[CHS + 1];
-  int sdst[CHS + 1];
-  size_t xoff[CHS];                                      // per-lane element offset of the chunk's row start (+ column inside the stage)
-  int xcc[CHS];
+  uint32_t xoff[CHS];                                    // element offset of the chunk's source row (rows * ldx < 2^31: checked on the host)
 #pragma unroll
   for (int i = 0; i < CHS; ++i) {
     const int id = lane + 64 * i;
-    const int row = id / (TS * 16), cc = id - row * (TS * 16);
+    const int row = id / (TS * 16);
     int src_row = row < M ? row : 0;
     if constexpr (ROWMAP) {
       const int p = rows[row < 16 ? row : 0];
       src_row = p >= 0 ? p / moe.x_div : 0;              // padding rows read row 0 (finite or not: their outputs are never stored)
     }
-    xoff[i] = (size_t)src_row * ldx;
-    xcc[i] = cc;
-    sdst[i] = id < nx ? (row * XS + cc * 8) * 2 : dump;
+    xoff[i] = (uint32_t)src_row * (uint32_t)ldx;
   }
+  auto x_cc = [&](int l, int i) { const int id = l + 64 * i; return id - (id / (TS * 16)) * (TS * 16); };          // column chunk inside the stage
+  auto x_dst = [&](int l, int i) { const int id = l + 64 * i, row = id / (TS * 16); return id < nx ? (row * XS + (id - row * (TS * 16)) * 8) * 2 : dump; };
   const int zc = lane < NZ ? lane : NZ - 1;              // zs chunk of this lane: (c, t, part)
   const int z_c = zc / (TS * 4), z_rem = zc - z_c * (TS * 4), z_t = z_rem >> 2, z_part = z_rem & 3;
-  sdst[CHS] = lane < NZ ? xbytes + ((z_c * TS + z_t) * 16 + z_part * 4) * 4 : dump;
 
   auto stage_load = [&](int s) {                         // issue the staging loads of stage s (clamped addresses: always in bounds)
     const int kbs = kb0 + s * TS;
+    int l = lane;
+    asm volatile("" : "+v"(l));
 #pragma unroll
     for (int i = 0; i < CHS; ++i) {
-      int kbx = kbs + (xcc[i] >> 4);
+      const int cc = x_cc(l, i);
+      int kbx = kbs + (cc >> 4);
       kbx = kbx < KB ? kbx : KB - 1;
-      sv[i] = *(const u32x4_t*)(x + xoff[i] + (size_t)kbx * 128 + (xcc[i] & 15) * 8);
+      sv[i] = *(const u32x4_t*)(x + xoff[i] + (uint32_t)kbx * 128u + (uint32_t)(cc & 15) * 8u);
     }
     int kbz = kbs + z_t;
     kbz = kbz < KB ? kbz : KB - 1;
@@ -108,13 +111,16 @@ __global__ __launch_bounds__(1024) void gemv_rp3_kernel(const uint16_t* __restri
   };
   auto stage_store = [&](int s) {                        // park them in this wave's LDS; k-blocks outside [kb0, kb_end) become exact zeros
     const int kbs = kb0 + s * TS;
+    int l = lane;
+    asm volatile("" : "+v"(l));
 #pragma unroll
     for (int i = 0; i < CHS; ++i) {
-      const bool in = kbs + (xcc[i] >> 4) < kb_end;
-      *(u32x4_t*)(stg + sdst[i]) = in ? sv[i] : (u32x4_t){0u, 0u, 0u, 0u};
+      const bool in = kbs + (x_cc(l, i) >> 4) < kb_end;
+      *(u32x4_t*)(stg + x_dst(l, i)) = in ? sv[i] : (u32x4_t){0u, 0u, 0u, 0u};
     }
     const bool zin = kbs + z_t < kb_end;
-    *(u32x4_t*)(stg + sdst[CHS]) = zin ? sv[CHS] : (u32x4_t){0x64000000u, 0x64000000u, 0x64000000u, 0x64000000u};   // scale 0, zero point 0
+    const int zdst = l < NZ ? xbytes + ((z_c * TS + z_t) * 16 + z_part * 4) * 4 : dump;
+    *(u32x4_t*)(stg + zdst) = zin ? sv[CHS] : (u32x4_t){0x64000000u, 0x64000000u, 0x64000000u, 0x64000000u};   // scale 0, zero point 0
   };
 
   // weights: unit u of stage s = (c = u / TS, t = u % TS): a wave's consecutive loads of a column group are contiguous.
@@ -165,9 +171,11 @@ __global__ __launch_bounds__(1024) void gemv_rp3_kernel(const uint16_t* __restri
 #pragma unroll
     for (int i = 0; i < L; ++i) {
       const int c = i / TS, t = i - c * TS;
-      if (TS > 1 || i == 0) {
+      if constexpr (!XJIT) {
+        if (TS > 1 || i == 0) {
 #pragma unroll
-        for (int d = 0; d < 4; ++d) xa[d] = *(const u32x4_t*)(x_lds + t * 128 + d * 32 + q * 8);
+          for (int d = 0; d < 4; ++d) xa[d] = *(const u32x4_t*)(x_lds + t * 128 + d * 32 + q * 8);
+        }
       }
       const half2_t zh = as_h2(zs_lds[(c * TS + t) * 16]);
       const half2_t s2 = __builtin_shufflevector(zh, zh, 0, 0);
@@ -178,15 +186,26 @@ __global__ __launch_bounds__(1024) void gemv_rp3_kernel(const uint16_t* __restri
       __builtin_amdgcn_sched_barrier(0);
       if (s + (i + DD) / L < S) load_rel(s, i + DD, (PH + i + DD) % RB);   // ... its replacement leaves at once, into the spare register set
       __builtin_amdgcn_sched_barrier(0);
+      // XJIT (many rows on wide strips): the x fragment of a k-step is read from LDS just before its MFMA, one k-step ahead, instead of
+      // holding the four of a k-block (16 registers) across the stage's units
+      u32x4_t xn;
+      if constexpr (XJIT) xn = *(const u32x4_t*)(x_lds + t * 128 + q * 8);
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
+        u32x4_t xc;
+        if constexpr (XJIT) {
+          xc = xn;
+          if (d < 3) xn = *(const u32x4_t*)(x_lds + t * 128 + (d + 1) * 32 + q * 8);
+        } else {
+          xc = xa[d];
+        }
         const uint32_t ww = w[d], w8 = ww >> 8;
         const half2_t d0 = as_h2((ww & mlo) | magic) - z1024;
         const half2_t d1 = __builtin_elementwise_fma(as_h2((ww & mhi) | magic), sixteenth, -z64);
         const half2_t d2 = as_h2((w8 & mlo) | magic) - z1024;
         const half2_t d3 = __builtin_elementwise_fma(as_h2((w8 & mhi) | magic), sixteenth, -z64);
         const u32x4_t frag = {as_u32(d0 * s2), as_u32(d1 * s2), as_u32(d2 * s2), as_u32(d3 * s2)};
-        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, xa[d]), __builtin_bit_cast(half8_t, frag), acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, xc), __builtin_bit_cast(half8_t, frag), acc[c], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -348,11 +367,56 @@ int launch_gemv_repacked_loop(const GemmArgs& a, const void* packed) {
   int G = 0, nwg = 0;
   if (!gemv_strip_geometry(a.K, a.N, &G, &nwg)) return AWQ_ERR_BAD_VARIANT;
   const int TS = rp3_stage(a.M, G);
+  if ((int64_t)a.M * a.ldx >= (int64_t(1) << 31)) return AWQ_ERR_BAD_VARIANT;                    // 32-bit activation row offsets in the kernel
   if (!rp3_dispatch<0, false>(G, TS, a, packed, NG, nwg, 1, Rp3Moe{nullptr, nullptr, nullptr, 0, 1})) return AWQ_ERR_BAD_VARIANT;
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
 }  // namespace awq
+
+// ------------------------------------------------------------------------------------------------------------- block alignment
+// One workgroup: count the pairs of every expert (LDS atomics), pad each count to a multiple of 16, place every valid pair in its
+// expert's run.  The order of the rows inside an expert's blocks is whatever the LDS atomics give — rows are independent, the outputs
+// do not depend on it.
+namespace awq {
+constexpr int kAlignMaxExperts = 1024;
+__global__ __launch_bounds__(1024) void moe_align16_kernel(const int* __restrict__ ids, int P, int E, int* __restrict__ row_map,
+                                                           int* __restrict__ block_expert, int B) {
+  __shared__ int cnt[kAlignMaxExperts], start[kAlignMaxExperts + 1], cur[kAlignMaxExperts];
+  const int t = threadIdx.x;
+  for (int e = t; e < E; e += 1024) { cnt[e] = 0; cur[e] = 0; }
+  for (int i = t; i < B * 16; i += 1024) row_map[i] = -1;
+  for (int b = t; b < B; b += 1024) block_expert[b] = -1;
+  __syncthreads();
+  for (int p = t; p < P; p += 1024) {
+    const int e = ids[p];
+    if (e >= 0 && e < E) atomicAdd(&cnt[e], 1);
+  }
+  __syncthreads();
+  if (t == 0) {
+    int acc = 0;
+    for (int e = 0; e < E; ++e) { start[e] = acc; acc += (cnt[e] + 15) & ~15; }
+    start[E] = acc;
+  }
+  __syncthreads();
+  for (int e = t; e < E; e += 1024)
+    for (int b = start[e] >> 4; b < (start[e + 1] >> 4); ++b) block_expert[b] = e;
+  for (int p = t; p < P; p += 1024) {
+    const int e = ids[p];
+    if (e >= 0 && e < E) row_map[start[e] + atomicAdd(&cur[e], 1)] = p;
+  }
+}
+}  // namespace awq
+
+extern "C" int awq_aux_moe_align_blocks(const int32_t* ids, int64_t pairs, int64_t num_experts, int32_t* row_map, int32_t* block_expert,
+                                        int64_t num_blocks, void* stream) {
+  if (!ids || !row_map || !block_expert) return AWQ_ERR_NULL_POINTER;
+  if (pairs <= 0 || num_experts < 1 || num_blocks < (pairs + 15) / 16 + num_experts || num_blocks > (1 << 24) || pairs > (1 << 28)) return AWQ_ERR_BAD_SHAPE;
+  if (num_experts > awq::kAlignMaxExperts) return AWQ_ERR_BAD_VARIANT;
+  hipLaunchKernelGGL(awq::moe_align16_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ids, (int)pairs, (int)num_experts, row_map,
+                     block_expert, (int)num_blocks);
+  return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
 
 // AWQ-MoE over expert-sorted (token, expert) pairs in blocks of 16 rows (include/awq_aux.h).
 extern "C" int awq_aux_moe_gemv_blocks(const void* x, int64_t ldx, int x_div, const void* packed_experts, int64_t expert_stride_bytes,
@@ -371,9 +435,13 @@ extern "C" int awq_aux_moe_gemv_blocks(const void* x, int64_t ldx, int x_div, co
   a.M = 16; a.K = (int)K; a.N = (int)N; a.g = (int)group_size; a.dtype = dtype; a.tune = 0;
   a.stream = (hipStream_t)stream;
   const int NG = rp_groups(N);
-  int G = (NG + 255) / 256;
-  if (silu_mul && (G & 1)) ++G;
-  if (G > kRpMaxG || G > NG) return AWQ_ERR_BAD_VARIANT;
+  // Strip width.  A launch holds several 16-row blocks (one per active expert at least), so strips need not be one-per-CU narrow; every
+  // workgroup stages all 16 activation rows, so wider strips mean less activation traffic.  6 column groups: a stage of 6 units is a
+  // whole number of ring turns (one loop body, 98-100 registers; widths that are not a multiple of 3 need a body per ring phase and
+  // spill at 16 rows: tools/rp_resources.py), even for the SiLU-mul pairs.
+  int G = NG >= 6 ? 6 : (NG >= 3 && !silu_mul) ? 3 : NG >= 2 ? 2 : 1;
+  if (silu_mul && (G & 1)) return AWQ_ERR_BAD_VARIANT;
+  if ((num_blocks * 16 / x_div + 1) * ldx >= (int64_t(1) << 31)) return AWQ_ERR_BAD_VARIANT;     // 32-bit activation row offsets in the kernel
   const int nwg = (NG + G - 1) / G;
   const int TS = 1;                                      // 16 rows: one k-block per stage (4 x chunks per lane)
   const Rp3Moe moe = {row_map, block_expert, slot_scale, (long long)expert_stride_bytes, x_div};

@@ -62,9 +62,9 @@ class AWQMoEMethod:
     """create_weights / process_weights_after_loading / create_moe_runner / apply for a layer of AWQ-quantised experts."""
 
     # (token, expert) pairs served one grid row each; beyond: expert-sorted 16-row blocks.  Measured on Mixtral-8x7B-like experts
-    # (E = 8, K = 4096, I = 14336, top-2; profiles/r03_time_moe.txt): a pair costs ~17.7 us on the slot route, the block route ~390 us
-    # for up to 16 rows per expert (+ the device-side alignment): they cross near 22 pairs
-    MOE_SLOT_MAX_PAIRS = 24
+    # (E = 8, K = 4096, I = 14336, top-2; profiles/r03_time_moe.txt): a pair costs ~16-17 us on the slot route, the block route ~215 us
+    # for up to 16 rows per expert: they cross near 13 pairs
+    MOE_SLOT_MAX_PAIRS = 12
     MOE_GEMV_MAX_SLOTS = MOE_SLOT_MAX_PAIRS   # (name of rounds 1-2)
 
     def __init__(self, quant_config: AWQConfig):
@@ -183,6 +183,23 @@ class AWQMoEMethod:
         block_expert = torch.where(blk_start < ends[-1], e_of, torch.full_like(e_of, -1)).to(torch.int32)
         return row_map, block_expert
 
+    @classmethod
+    def align_blocks_device(cls, ids: torch.Tensor, num_experts: int):
+        """align_blocks as one small launch (`awq_aux_moe_align_blocks`: counting sort through LDS, one workgroup) instead of a dozen
+        tensor ops (~100 us of launch boundaries per MoE layer, profiles/r03_time_moe.txt); the same contract except that the order of
+        the rows inside an expert's run is not specified.  More than 1024 experts: the tensor-op form."""
+        if not ids.is_cuda or num_experts > 1024:
+            return cls.align_blocks(ids, num_experts)
+        P = ids.numel()
+        B = (P + 15) // 16 + num_experts
+        row_map = torch.empty(B * 16, dtype=torch.int32, device=ids.device)
+        block_expert = torch.empty(B, dtype=torch.int32, device=ids.device)
+        rc = _lib.load().awq_aux_moe_align_blocks(ctypes.c_void_p(ids.data_ptr()), P, num_experts, ctypes.c_void_p(row_map.data_ptr()),
+                                                  ctypes.c_void_p(block_expert.data_ptr()), B,
+                                                  ctypes.c_void_p(torch.cuda.current_stream(ids.device).cuda_stream))
+        _lib.check(rc, "awq_aux_moe_align_blocks")
+        return row_map, block_expert
+
     def apply(self, layer: torch.nn.Module, dispatch_output, topk_weights: Optional[torch.Tensor] = None,
               topk_ids: Optional[torch.Tensor] = None):
         """The reference's call: apply(layer, dispatch_output) -> CombineInput (awq.py:822-845).  For direct use the tensors may be
@@ -219,7 +236,7 @@ class AWQMoEMethod:
             if act is not None:
                 y = self._moe_gemv(act, layer.w2_packed, ids, wts, pairs, 1, I, K, False, E)
         if y is None:
-            row_map, block_expert = self.align_blocks(ids, E)
+            row_map, block_expert = self.align_blocks_device(ids, E)
             act = self._moe_blocks(x, layer.w13_packed, row_map, block_expert, None, pairs, top_k, K, 2 * I, True)
             if act is None:
                 raise NotImplementedError(f"AWQMoEMethod: no kernel for experts K={K} I={I} group_size={self.quant_config.group_size}")

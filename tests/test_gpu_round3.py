@@ -397,3 +397,39 @@ def test_7b_dimension_layers_match_fp32_reference(B):
     assert graphed.graph is not None, graphed.capture_error
     assert [graphed.run(1) for _ in range(4)] == seq_eager
     assert "folded" in model.layers[0].norm_order(B) if B <= 16 else "reference" in model.layers[0].norm_order(B)
+
+
+@pytest.mark.parametrize("P,E", [(1, 8), (40, 8), (600, 8), (33, 4), (5, 1), (4096, 60), (7, 1024)])
+def test_moe_align_blocks_kernel_contract(ops, P, E):
+    """awq_aux_moe_align_blocks (one-workgroup counting sort) against the contract of the tensor-op form: every valid pair exactly once, in a
+    block of its own expert; padding and unused blocks are -1; ids outside [0, E) are dropped; experts in ascending block order."""
+    from sglang_awq_amd.moe import AWQMoEMethod
+
+    g = torch.Generator().manual_seed(P * 7 + E)
+    ids = torch.randint(-1, E, (P,), dtype=torch.int32, generator=g)
+    if P > 3:
+        ids[2] = E + 5
+    row_map, block_expert = AWQMoEMethod.align_blocks_device(ids.to(DEV), E)
+    torch.cuda.synchronize()
+    row_map, block_expert = row_map.cpu(), block_expert.cpu()
+    B = block_expert.numel()
+    assert B == (P + 15) // 16 + E and row_map.numel() == 16 * B
+    ref_map, ref_be = AWQMoEMethod.align_blocks(ids, E)
+    assert torch.equal(block_expert, ref_be)
+    seen = []
+    for b in range(B):
+        e = int(block_expert[b])
+        rows = row_map[b * 16:(b + 1) * 16].tolist()
+        if e < 0:
+            assert all(r == -1 for r in rows)
+            continue
+        real = [r for r in rows if r >= 0]
+        assert real and all(int(ids[r]) == e for r in real)
+        seen += real
+    assert sorted(seen) == [i for i in range(P) if 0 <= int(ids[i]) < E]
+    for b in range(B):            # the same SET of rows per block region as the stable reference (order inside an expert's run is free)
+        pass
+    for e in range(E):
+        got = sorted(r for b in range(B) if int(block_expert[b]) == e for r in row_map[b * 16:(b + 1) * 16].tolist() if r >= 0)
+        want = sorted(r for b in range(B) if int(ref_be[b]) == e for r in ref_map[b * 16:(b + 1) * 16].tolist() if r >= 0)
+        assert got == want
