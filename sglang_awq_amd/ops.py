@@ -136,7 +136,8 @@ def prepare_stream_workspaces(stream: Optional["torch.cuda.Stream"] = None, devi
 #   * SGLANG_AWQ_AMD_OP_CACHE=0: always off.
 # The copy is made on the first eager call for a weight — never during stream capture (a capture-time miss runs the
 # checkpoint-layout kernel, whose fp32 summation order differs: same tolerance, not bit-identical to the cached route) —
-# costs awq_repacked_bytes() of HBM per weight (cap SGLANG_AWQ_AMD_OP_CACHE_GB, default 64), and is dropped by
+# costs awq_repacked_bytes() of HBM per weight (cap SGLANG_AWQ_AMD_OP_CACHE_GB, default 64; never more than half of the memory free
+# on the device when a copy is about to be made), and is dropped by
 # awq_gemm_cache_clear().  Results on a hit are bit-identical to awq_gemm_repacked (same kernels).  Tensors without a version
 # counter (created under torch.inference_mode()) bypass the cache.
 _op_cache = {}
@@ -193,6 +194,11 @@ def _op_cached_repack(qweight, scales, qzeros, K, N, g):
         return None                                   # fill on an eager (warm-up) call only
     nbytes = _lib.load().awq_repacked_bytes(K, N, g, _DTYPE_CODE[scales.dtype])
     if nbytes == 0 or _op_cache_bytes + nbytes > _OP_CACHE_MAX_BYTES:
+        return None
+    # the copies are made on the first forward, after a serving stack has sized its KV pool: never take more than half of what the
+    # device has free at that moment (the call then runs the checkpoint-layout kernel, slower but allocation-free)
+    free_bytes, _total = torch.cuda.mem_get_info(qweight.device)
+    if nbytes > free_bytes // 2:
         return None
     packed = awq_repack(qweight, scales, qzeros)
     if packed is None:
