@@ -302,10 +302,19 @@ def main():
     capture_error = None
     graphs = {}
 
+    cap_stream = None
+
     def capture(n, fn=step):
+        nonlocal cap_stream
+        if cap_stream is None:
+            # one capture stream for every graph of this run, with the ops' per-stream scratch created eagerly on it (a first use
+            # inside a capture raises: sglang_awq_amd/ops.py)
+            cap_stream = torch.cuda.Stream()
+            cap_stream.wait_stream(torch.cuda.current_stream())
+            ops.prepare_stream_workspaces(cap_stream, dev)
         g = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread may touch the runtime while this thread captures (N > 1)
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        with torch.cuda.graph(g, stream=cap_stream, capture_error_mode="thread_local"):
             for i in range(n):
                 fn(i)
         return g
@@ -393,9 +402,7 @@ def main():
         """us per launch of `fn_pass` (a pass over the rotating weight sets) replayed from a graph between HIP events."""
         fn_pass()
         sync()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            fn_pass()
+        g = capture(1, lambda _i: fn_pass())
         for _ in range(2):
             g.replay()
         sync()
