@@ -280,7 +280,9 @@ class GraphedDecoder:
         layer = self.model.layers[0]
         splits = 1
         if self.start_pos >= 384:
-            splits = max(1, min(16, 256 // max(1, self.batch * layer.num_heads)))
+            # measured at context 1024 (7B, 32 heads; step time at 2 / 4 / 8 / 16 splits): batch 1: 1.410 / 1.347 / 1.316 / 1.343 ms,
+            # batch 2: 1.511 / 1.463 / 1.449 / 1.535, batch 4: 1.694 / 1.673 / 1.683 / 1.751 -> two workgroups per CU, at most 8 splits
+            splits = max(1, min(8, 512 // max(1, self.batch * layer.num_heads)))
         for lyr in self.model.layers:
             lyr.attn_splits = splits
 

@@ -351,8 +351,8 @@ def test_7b_dimension_layers_match_fp32_reference(B):
     gen = torch.Generator(device=DEV); gen.manual_seed(5)
     past_k = [(torch.randn(B, l.num_kv_heads, P0, cfg.head_dim, device=DEV, generator=gen) * 0.5).half() for l in model.layers]
     past_v = [(torch.randn(B, l.num_kv_heads, P0, cfg.head_dim, device=DEV, generator=gen) * 0.5).half() for l in model.layers]
-    splits = max(1, min(16, 256 // (B * model.layers[0].num_heads)))          # what GraphedDecoder picks at this context
-    assert splits == (8 if B == 1 else 1)
+    splits = max(1, min(8, 512 // (B * model.layers[0].num_heads)))           # what GraphedDecoder picks at this context
+    assert splits == {1: 8, 8: 2, 32: 1}[B]
 
     def reset_caches():
         for l, pk, pv in zip(model.layers, past_k, past_v):
