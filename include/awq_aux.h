@@ -23,7 +23,8 @@ int awq_aux_add_rmsnorm(void* h, const void* delta, const void* w, void* out, in
  * out[B, Hq D] = softmax(scale q K^T) V over cache slots 0..pos[b].  D in {64, 128}, Hq % Hkv == 0.
  * num_splits (1..16) workgroups share each (sequence, head), splitting the context ("flash-decoding"; use > 1 when B * Hq is
  * well below the 256 CUs and the context is long); it needs `workspace` of awq_aux_decode_attention_workspace_bytes(...) bytes,
- * 16-byte aligned, zero-filled ONCE at allocation (tickets; every call leaves them zero), one per stream of execution. */
+ * 16-byte aligned, zero-filled ONCE at allocation (tickets in a fixed 64 KiB header; every call leaves them zero — the same buffer
+ * may serve calls of different batch sizes and split counts), one per stream of execution; B * Hq <= 16384 with num_splits > 1. */
 size_t awq_aux_decode_attention_workspace_bytes(int64_t B, int64_t Hq, int64_t D, int num_splits);
 int awq_aux_decode_attention(const void* qkv, const int64_t* pos, const float* cos_table, const float* sin_table, void* k_cache,
                              void* v_cache, void* out, int64_t B, int64_t Hq, int64_t Hkv, int64_t D, int64_t S, float scale,

@@ -360,6 +360,9 @@ int awq_aux_add_rmsnorm(void* h, const void* delta, const void* w, void* out, in
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
+constexpr int64_t kAttnMaxTickets = 16384;                          // (sequence, head) pairs a split-S call may have
+constexpr size_t kAttnTicketBytes = (size_t)kAttnMaxTickets * sizeof(unsigned);
+
 int awq_aux_decode_attention(const void* qkv, const int64_t* pos, const float* cos_t, const float* sin_t, void* k_cache, void* v_cache,
                              void* out, int64_t B, int64_t Hq, int64_t Hkv, int64_t D, int64_t S, float scale, int num_splits,
                              void* workspace, size_t workspace_bytes, void* stream) {
@@ -369,9 +372,13 @@ int awq_aux_decode_attention(const void* qkv, const int64_t* pos, const float* c
   unsigned* cnt = nullptr;
   if (num_splits > 1) {
     if (!workspace || (((uintptr_t)workspace) & 15)) return AWQ_ERR_WORKSPACE;
+    if (B * Hq > kAttnMaxTickets) return AWQ_ERR_BAD_VARIANT;       // (callers run one workgroup per head there: the grid already fills the chip)
     if (workspace_bytes < awq_aux_decode_attention_workspace_bytes(B, Hq, D, num_splits)) return AWQ_ERR_WORKSPACE;
-    cnt = (unsigned*)workspace;                                     // [B * Hq] tickets, zero once at allocation; left zero by every call
-    part = (float*)((char*)workspace + (((size_t)B * Hq * sizeof(unsigned) + 255) & ~(size_t)255));
+    // [kAttnMaxTickets] tickets in a header of FIXED size, zero once at allocation and left zero by every call, then the partials.
+    // (The header used to be B * Hq words: a call with a larger batch than an earlier one on the same workspace then found the
+    // earlier call's partials where its tickets should have been zero — wrong results from batch 4 at 2..8 splits; round 3.)
+    cnt = (unsigned*)workspace;
+    part = (float*)((char*)workspace + kAttnTicketBytes);
   }
   const dim3 grid((unsigned)Hq, (unsigned)B, (unsigned)num_splits), block(256);
 #define AWQ_ATTN_GO(DD)                                                                                                          \
@@ -384,7 +391,7 @@ int awq_aux_decode_attention(const void* qkv, const int64_t* pos, const float* c
 
 size_t awq_aux_decode_attention_workspace_bytes(int64_t B, int64_t Hq, int64_t D, int num_splits) {
   if (num_splits <= 1 || B <= 0 || Hq <= 0 || D <= 0) return 0;
-  return (((size_t)B * Hq * sizeof(unsigned) + 255) & ~(size_t)255) + (size_t)B * Hq * num_splits * (D + 2) * sizeof(float);
+  return kAttnTicketBytes + (size_t)B * Hq * num_splits * (D + 2) * sizeof(float);
 }
 
 int awq_aux_argmax_advance(const void* logits, int64_t* tokens, int64_t* pos, int64_t B, int64_t V, void* stream) {

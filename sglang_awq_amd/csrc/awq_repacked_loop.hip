@@ -284,29 +284,26 @@ __global__ __launch_bounds__(1024) void gemv_rp3_kernel(const uint16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------------------- host
-static int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
-
-// stage depth for (rows, strip width): staging of <= 4 x chunks per lane (rows * TS <= 16), a stage of <= 16 units
-static int rp3_stage(int M, int G) {
-  int ts = 16 / pow2_ceil(M);
-  if (ts > 4) ts = 4;
-  while (ts > 1 && G * ts > 16) ts >>= 1;
-  return ts;
-}
 static size_t rp3_lds(int M, int G, int TS) {
   const size_t stage = (size_t)16 * ((size_t)M * (TS * 128 + 8) * 2 + (size_t)G * TS * 64 + 16);
   const size_t redb = (size_t)16 * M * 16 * G * sizeof(float);
   return stage > redb ? stage : redb;
 }
 
-template <int G, int TS, int EPI, bool ROWMAP>
+// Instantiations: only what the dispatcher takes (awq_dispatch.h) — 9..16 rows (four staging chunks per lane, one k-block per stage) on
+// strips of 1 or 2 column groups for the plain operator; 16-row blocks on strips of 6 / 3 / 2 / 1 column groups for the AWQ-MoE.  The
+// template itself is general (stages of 1, 2 or 4 k-blocks, 1..16 rows, strips up to 8 groups: the round-3 A/B built all of them,
+// profiles/r03_kbench_rp3_ab.txt); widths whose stage is not a whole number of ring turns need a loop body per ring phase and, beyond
+// 2 groups at 16 rows, spill.
+template <int G, int EPI, bool ROWMAP>
 static bool rp3_go(const GemmArgs& a, const void* packed, int NG, int nwg, int ny, const Rp3Moe& moe) {
-  if constexpr (G * TS > 16 || (EPI == 1 && (G & 1))) {
+  if constexpr (EPI == 1 && (G & 1)) {
     return false;
   } else {
+    constexpr int TS = 1, CHS = 4;
     const int M = ROWMAP ? 16 : a.M;
     const size_t lds = rp3_lds(M, G, TS);
-    if (lds > (size_t)kRpMaxLds) return false;
+    if (lds > (size_t)kRpMaxLds || M < 9 || M > 16) return false;
     const u32x4_t* qw_r = (const u32x4_t*)packed;
     const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
     const int KB = a.K / 128, T = (KB + 15) / 16;
@@ -314,48 +311,13 @@ static bool rp3_go(const GemmArgs& a, const void* packed, int NG, int nwg, int n
     int lg = 0;
     while ((1 << lg) < gk) ++lg;
     const int gshift = 12 + lg, gmul = (int)(((1ll << gshift) + gk - 1) / gk);
-#define RP3_LAUNCH(CHS, ONE)                                                                                                         \
-    do {                                                                                                                             \
-      auto kern = gemv_rp3_kernel<G, TS, CHS, EPI, ONE, ROWMAP>;                                                                     \
-      static unsigned long long opted[2] = {0ull, 0ull};                                                                             \
-      if (lds > 64 * 1024 && !opt_in_dynamic_lds((const void*)kern, kRpMaxLds, opted)) return false;                                  \
-      hipLaunchKernelGGL(kern, dim3(nwg, ny), dim3(1024), lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r, a.bias, a.y, M, a.K,   \
-                         a.N, a.K / a.g, gmul, gshift, NG, T, moe);                                                                   \
-      return true;                                                                                                                   \
-    } while (0)
-    const int chunks = (pow2_ceil(M) * TS * 16 + 63) / 64;           // x chunks per lane: 1, 2 or 4
-    if constexpr (!ROWMAP) {
-      if (M == 1 && chunks == 1) RP3_LAUNCH(1, true);
-    }
-    if (chunks == 1) RP3_LAUNCH(1, false);
-    if (chunks == 2) RP3_LAUNCH(2, false);
-    if (chunks == 4) RP3_LAUNCH(4, false);
-#undef RP3_LAUNCH
-    return false;
+    auto kern = gemv_rp3_kernel<G, TS, CHS, EPI, false, ROWMAP>;
+    static unsigned long long opted[2] = {0ull, 0ull};
+    if (lds > 64 * 1024 && !opt_in_dynamic_lds((const void*)kern, kRpMaxLds, opted)) return false;
+    hipLaunchKernelGGL(kern, dim3(nwg, ny), dim3(1024), lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r, zs_r, a.bias, a.y, M, a.K, a.N,
+                       a.K / a.g, gmul, gshift, NG, T, moe);
+    return true;
   }
-}
-
-template <int EPI, bool ROWMAP>
-static bool rp3_dispatch(int G, int TS, const GemmArgs& a, const void* packed, int NG, int nwg, int ny, const Rp3Moe& moe) {
-#define RP3_TS(GG)                                                                                  \
-  switch (TS) {                                                                                     \
-    case 1: return rp3_go<GG, 1, EPI, ROWMAP>(a, packed, NG, nwg, ny, moe);                          \
-    case 2: return rp3_go<GG, 2, EPI, ROWMAP>(a, packed, NG, nwg, ny, moe);                          \
-    case 4: return rp3_go<GG, 4, EPI, ROWMAP>(a, packed, NG, nwg, ny, moe);                          \
-    default: return false;                                                                          \
-  }
-  switch (G) {
-    case 1: RP3_TS(1)
-    case 2: RP3_TS(2)
-    case 3: RP3_TS(3)
-    case 4: RP3_TS(4)
-    case 5: RP3_TS(5)
-    case 6: RP3_TS(6)
-    case 7: RP3_TS(7)
-    case 8: RP3_TS(8)
-    default: return false;
-  }
-#undef RP3_TS
 }
 
 // The plain operator on the loop form: M <= 16, fp16, g % 128 == 0, at least 16 k-blocks; AWQ_ERR_BAD_VARIANT when the shape has no
@@ -366,9 +328,11 @@ int launch_gemv_repacked_loop(const GemmArgs& a, const void* packed) {
   if (KB < 16 || KB >= 4096 || a.g / 128 >= 4096) return AWQ_ERR_BAD_VARIANT;
   int G = 0, nwg = 0;
   if (!gemv_strip_geometry(a.K, a.N, &G, &nwg)) return AWQ_ERR_BAD_VARIANT;
-  const int TS = rp3_stage(a.M, G);
+  if (a.M < 9 || G > 2) return AWQ_ERR_BAD_VARIANT;      // what is instantiated (the dispatcher asks for 13..16 rows on <= 2 groups)
   if ((int64_t)a.M * a.ldx >= (int64_t(1) << 31)) return AWQ_ERR_BAD_VARIANT;                    // 32-bit activation row offsets in the kernel
-  if (!rp3_dispatch<0, false>(G, TS, a, packed, NG, nwg, 1, Rp3Moe{nullptr, nullptr, nullptr, 0, 1})) return AWQ_ERR_BAD_VARIANT;
+  const Rp3Moe none = {nullptr, nullptr, nullptr, 0, 1};
+  const bool ok = G == 1 ? rp3_go<1, 0, false>(a, packed, NG, nwg, 1, none) : rp3_go<2, 0, false>(a, packed, NG, nwg, 1, none);
+  if (!ok) return AWQ_ERR_BAD_VARIANT;
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
@@ -443,10 +407,12 @@ extern "C" int awq_aux_moe_gemv_blocks(const void* x, int64_t ldx, int x_div, co
   if (silu_mul && (G & 1)) return AWQ_ERR_BAD_VARIANT;
   if ((num_blocks * 16 / x_div + 1) * ldx >= (int64_t(1) << 31)) return AWQ_ERR_BAD_VARIANT;     // 32-bit activation row offsets in the kernel
   const int nwg = (NG + G - 1) / G;
-  const int TS = 1;                                      // 16 rows: one k-block per stage (4 x chunks per lane)
   const Rp3Moe moe = {row_map, block_expert, slot_scale, (long long)expert_stride_bytes, x_div};
-  const bool ok = silu_mul ? rp3_dispatch<1, true>(G, TS, a, packed_experts, NG, nwg, (int)num_blocks, moe)
-                           : rp3_dispatch<0, true>(G, TS, a, packed_experts, NG, nwg, (int)num_blocks, moe);
+  const int nb = (int)num_blocks;
+  bool ok = false;
+  if (silu_mul) ok = G == 6 ? rp3_go<6, 1, true>(a, packed_experts, NG, nwg, nb, moe) : rp3_go<2, 1, true>(a, packed_experts, NG, nwg, nb, moe);
+  else ok = G == 6 ? rp3_go<6, 0, true>(a, packed_experts, NG, nwg, nb, moe) : G == 3 ? rp3_go<3, 0, true>(a, packed_experts, NG, nwg, nb, moe)
+          : G == 2 ? rp3_go<2, 0, true>(a, packed_experts, NG, nwg, nb, moe) : rp3_go<1, 0, true>(a, packed_experts, NG, nwg, nb, moe);
   if (!ok) return AWQ_ERR_BAD_VARIANT;
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }

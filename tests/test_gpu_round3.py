@@ -433,3 +433,29 @@ def test_moe_align_blocks_kernel_contract(ops, P, E):
         got = sorted(r for b in range(B) if int(block_expert[b]) == e for r in row_map[b * 16:(b + 1) * 16].tolist() if r >= 0)
         want = sorted(r for b in range(B) if int(ref_be[b]) == e for r in ref_map[b * 16:(b + 1) * 16].tolist() if r >= 0)
         assert got == want
+
+
+def test_split_s_attention_same_workspace_across_batch_sizes():
+    """The split-S decode attention keeps arrival tickets in its per-stream workspace.  A call with a larger batch than an earlier one on the
+    same workspace must still find them zero (round 3 bug: the ticket header was B * Hq words, so batch 4 after batch 1 read the earlier
+    call's partial sums as tickets — wrong results from batch 4 at 2..8 splits, NaN at batch 8).  Growing and shrinking batch sizes, every
+    split count against the single-workgroup result."""
+    from sglang_awq_amd import aux_ops
+
+    torch.manual_seed(0)
+    Hq = Hkv = 32
+    D, S = 128, 1040
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.float32, device=DEV) / D))
+    fr = torch.outer(torch.arange(S, dtype=torch.float32, device=DEV), inv)
+    cos_t, sin_t = fr.cos().contiguous(), fr.sin().contiguous()
+    for B in (1, 4, 2, 8, 16, 3):
+        pos = torch.full((B,), 1024, dtype=torch.int64, device=DEV)
+        qkv = torch.randn(B, (Hq + 2 * Hkv) * D, device=DEV).half()
+        kc0 = (torch.randn(B, Hkv, S, D, device=DEV) * 0.5).half()
+        vc0 = (torch.randn(B, Hkv, S, D, device=DEV) * 0.5).half()
+        ref = aux_ops.decode_attention(qkv, pos, cos_t, sin_t, kc0.clone(), vc0.clone(), Hq, Hkv, D, num_splits=1)
+        for splits in (2, 4, 8, 16):
+            for _ in range(2):
+                o = aux_ops.decode_attention(qkv, pos, cos_t, sin_t, kc0.clone(), vc0.clone(), Hq, Hkv, D, num_splits=splits)
+                assert torch.isfinite(o).all(), f"B={B} splits={splits}"
+                assert (o.float() - ref.float()).abs().max().item() <= 2e-3, f"B={B} splits={splits}"
