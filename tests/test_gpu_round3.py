@@ -459,3 +459,48 @@ def test_split_s_attention_same_workspace_across_batch_sizes():
                 o = aux_ops.decode_attention(qkv, pos, cos_t, sin_t, kc0.clone(), vc0.clone(), Hq, Hkv, D, num_splits=splits)
                 assert torch.isfinite(o).all(), f"B={B} splits={splits}"
                 assert (o.float() - ref.float()).abs().max().item() <= 2e-3, f"B={B} splits={splits}"
+
+
+def test_tiny_llama_long_context_every_batch_regime():
+    """The harness at a context where split-S attention is on (>= 384 positions in the cache), across the batch regimes of the GEMV dispatcher
+    (1, 2-8 folded norm, 9-16, 17-32 two row tiles, 33 = passes) with whatever split count GraphedDecoder picks, against the fp32 reference."""
+    from sglang_awq_amd import ops
+    from sglang_awq_amd.awq import AWQConfig
+    from sglang_awq_amd.llama import GraphedDecoder, LlamaConfig, LlamaForCausalLM
+    from tests.test_gpu_llama import _ref_step
+
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=4,
+                      vocab_size=512, max_position_embeddings=1024)
+    S, P0 = 448, 400
+    with torch.device(DEV):
+        model = LlamaForCausalLM(cfg, AWQConfig(4, 128, True), max_batch=33, max_seq=S)
+    model.init_synthetic_(seed=5)
+    W = [{name: ops.awq_dequantize(lin.qweight, lin.scales, lin.qzeros).float()
+          for name, lin in (("qkv", layer.qkv_proj), ("o", layer.o_proj), ("gate_up", layer.gate_up_proj), ("down", layer.down_proj))}
+         for layer in model.layers]
+    gen = torch.Generator(device=DEV); gen.manual_seed(9)
+    seen_splits = set()
+    with torch.no_grad():
+        for B in (1, 2, 5, 8, 9, 16, 17, 32, 33):
+            dec = GraphedDecoder(model, B, start_pos=P0)
+            dec._set_attention_splits()
+            seen_splits.add(model.layers[0].attn_splits)
+            past_k = [(torch.randn(B, l.num_kv_heads, P0, cfg.head_dim, device=DEV, generator=gen) * 0.5).half() for l in model.layers]
+            past_v = [(torch.randn(B, l.num_kv_heads, P0, cfg.head_dim, device=DEV, generator=gen) * 0.5).half() for l in model.layers]
+            kc = [torch.zeros(B, l.num_kv_heads, S, cfg.head_dim, device=DEV) for l in model.layers]
+            vc = [torch.zeros(B, l.num_kv_heads, S, cfg.head_dim, device=DEV) for l in model.layers]
+            for l, pk, pv, c1, c2 in zip(model.layers, past_k, past_v, kc, vc):
+                l.k_cache.zero_(); l.v_cache.zero_()
+                l.k_cache[:B, :, :P0] = pk; l.v_cache[:B, :, :P0] = pv
+                c1[:, :, :P0] = pk.float(); c2[:, :, :P0] = pv.float()
+            tokens = (torch.arange(B, device=DEV) * 37 + 5) % cfg.vocab_size
+            pos = torch.full((B,), P0, dtype=torch.int64, device=DEV) + (torch.arange(B, device=DEV) % 3)       # ragged positions
+            for step in range(2):
+                got = model.logits(tokens, pos).float()
+                want = _ref_step(model, W, tokens, pos, kc, vc)
+                scale = want.abs().max().item()
+                err = (got - want).abs().max().item()
+                assert err <= 2e-2 * scale + 2e-2, f"B={B} splits={model.layers[0].attn_splits} step {step}: {err} at scale {scale}"
+                tokens = want.argmax(-1)
+                pos = pos + 1
+    assert len(seen_splits) >= 3, seen_splits
