@@ -323,10 +323,17 @@ static int cmd_rgemm(int argc, char** argv) {
   void* ws = nullptr;
   const size_t ws_bytes = (getenv("KBENCH_WS") && atoi(getenv("KBENCH_WS")) == 0) ? 0 : awq_gemm_repacked_workspace_bytes(M, K, N, g, AWQ_DTYPE_F16);
   if (ws_bytes) { CK(hipMalloc(&ws, ws_bytes)); CK(hipMemset(ws, 0, ws_bytes)); }
+  // KBENCH_STREAMS=2 (probe): the launches of a graph alternate between two streams with no dependency between them — how much of the
+  // per-launch boundary + ramp disappears when the next kernel may start before the previous one has drained
+  const int nstreams = getenv("KBENCH_STREAMS") ? atoi(getenv("KBENCH_STREAMS")) : 1;
+  hipStream_t st2 = st; void* y2 = y;
+  if (nstreams > 1) { CK(hipStreamCreate(&st2)); CK(hipMalloc(&y2, (size_t)M * N * 2)); }
+  hipStream_t cur = st; void* ycur = y;
   auto launch = [&](int i) {
+    if (nstreams > 1) { cur = (i & 1) ? st2 : st; ycur = (i & 1) ? y2 : y; }
     int rc = fuse ? awq_aux_gemv_repacked_fused(x, K, packed[i % sets], y, M, K, N, g, AWQ_DTYPE_F16, (fuse & 1) ? x : nullptr, delta, nw, hout,
-                                                1e-5f, (fuse & 2) ? 1 : 0, st)
-                  : awq_gemm_repacked_ws(x, K, packed[i % sets], nullptr, y, ws, ws_bytes, M, K, N, g, AWQ_DTYPE_F16, st);
+                                                1e-5f, (fuse & 2) ? 1 : 0, cur)
+                  : awq_gemm_repacked_ws(x, K, packed[i % sets], nullptr, ycur, ws, ws_bytes, M, K, N, g, AWQ_DTYPE_F16, cur);
     if (rc) { fprintf(stderr, "awq_gemm_repacked: %s\n", awq_hip_status_string(rc)); exit(1); }
   };
   for (int i = 0; i < 2 * sets; ++i) launch(i);
@@ -337,7 +344,13 @@ static int cmd_rgemm(int argc, char** argv) {
     CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
     // launches per graph: at least 16 whatever `sets` is (a 1-launch graph times the replay overhead, not the kernel)
     const int glen = getenv("KBENCH_GLEN") ? atoi(getenv("KBENCH_GLEN")) : (sets < 16 ? 16 : sets);
+    hipEvent_t fork, join;
+    if (nstreams > 1) {
+      CK(hipEventCreate(&fork)); CK(hipEventCreate(&join));
+      CK(hipEventRecord(fork, st)); CK(hipStreamWaitEvent(st2, fork, 0));
+    }
     for (int i = 0; i < glen; ++i) launch(i);
+    if (nstreams > 1) { CK(hipEventRecord(join, st2)); CK(hipStreamWaitEvent(st, join, 0)); }
     CK(hipStreamEndCapture(st, &graph));
     CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     const int reps = (iters + glen - 1) / glen;
