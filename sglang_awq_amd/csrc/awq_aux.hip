@@ -96,7 +96,9 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(half_t* __restrict__ h
 // online softmax kept per 16-lane position group (LP = D / 8 lanes x 16 B per cached row, 256 / LP groups,
 // 4 positions per group in flight, the next block prefetched while the current one is reduced); the groups are
 // merged once through LDS.  No per-position storage: any context length.
-template <int D>
+// DBG (laboratory build only, tools/time_attn.py with AWQ_ATTN_DBG): 1 = no merge across splits (wrong results), 2 = pos not loaded,
+// 4 = every K / V row read is one of the first rows (cache-resident) — what each dependent piece of the launch costs.
+template <int D, int DBG = 0>
 __global__ __launch_bounds__(256) void decode_attention_kernel(const half_t* __restrict__ qkv, const int64_t* __restrict__ pos,
                                                                const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                                half_t* __restrict__ kc, half_t* __restrict__ vc,
@@ -130,12 +132,12 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const half_t* __r
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int j = sp * BLK + pg + u * NPG;
-    const int jc = j < S ? j : S - 1;
+    const int jc = (DBG & 4) ? pg : (j < S ? j : S - 1);
     kv[u] = *(const half8v*)(kbase + (size_t)jc * D + lp * 8);
     vv[u] = *(const half8v*)(vbase + (size_t)jc * D + lp * 8);
   }
 
-  const int64_t p_raw = pos[b];                                     // cached positions 0 .. p-1, the new token is p
+  const int64_t p_raw = (DBG & 2) ? (int64_t)(S - 64) : pos[b];                                     // cached positions 0 .. p-1, the new token is p
   // the host (GraphedDecoder) refuses to step past the cache; should a caller get here with p >= S anyway, clamp: the last
   // slot is overwritten and attended to, nothing outside the cache or the rotary tables is touched
   const int p = (int)(p_raw < 0 ? 0 : (p_raw < S ? p_raw : S - 1));
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const half_t* __r
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int j = j0 + ns * BLK + u * NPG;
-        const int jc = j < p ? j : (p > 0 ? p - 1 : 0);
+        const int jc = (DBG & 4) ? pg : (j < p ? j : (p > 0 ? p - 1 : 0));
         kn[u] = *(const half8v*)(kbase + (size_t)jc * D + lp * 8);
         vn[u] = *(const half8v*)(vbase + (size_t)jc * D + lp * 8);
       }
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const half_t* __r
       lt += l_s[g] * f;
     }
   }
-  if (ns == 1) {
+  if (ns == 1 || (DBG & 1)) {
     if (t < D) out[((size_t)b * Hq + h) * D + t] = (half_t)(o / lt);
     return;
   }
@@ -384,6 +386,18 @@ int awq_aux_decode_attention(const void* qkv, const int64_t* pos, const float* c
 #define AWQ_ATTN_GO(DD)                                                                                                          \
   hipLaunchKernelGGL(awq::decode_attention_kernel<DD>, grid, block, 0, (hipStream_t)stream, (const awq::half_t*)qkv, pos, cos_t,  \
                      sin_t, (awq::half_t*)k_cache, (awq::half_t*)v_cache, (awq::half_t*)out, (int)Hq, (int)Hkv, (int)S, scale, part, cnt)
+#ifdef AWQ_LAB
+  const int dbg = awq::lab_env("AWQ_ATTN_DBG", 0);
+#define AWQ_ATTN_DBG_GO(V)                                                                                                        \
+  if (D == 128 && dbg == V) {                                                                                                     \
+    hipLaunchKernelGGL((awq::decode_attention_kernel<128, V>), grid, block, 0, (hipStream_t)stream, (const awq::half_t*)qkv, pos, \
+                       cos_t, sin_t, (awq::half_t*)k_cache, (awq::half_t*)v_cache, (awq::half_t*)out, (int)Hq, (int)Hkv, (int)S,  \
+                       scale, part, cnt);                                                                                         \
+    return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;                                                             \
+  }
+  AWQ_ATTN_DBG_GO(1) AWQ_ATTN_DBG_GO(2) AWQ_ATTN_DBG_GO(3) AWQ_ATTN_DBG_GO(4) AWQ_ATTN_DBG_GO(6) AWQ_ATTN_DBG_GO(7)
+#undef AWQ_ATTN_DBG_GO
+#endif
   if (D == 128) AWQ_ATTN_GO(128); else AWQ_ATTN_GO(64);
 #undef AWQ_ATTN_GO
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;

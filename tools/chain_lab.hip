@@ -13,7 +13,7 @@
 // Shapes alternate 4096 -> 12288 (strips of 3 column groups, 2 k-blocks per wave) and 12288 -> 4096 (1 column group, 6 k-blocks per wave):
 // 256 workgroups each.  Every spin is bounded; a give-up raises an error flag and is reported.
 //
-//   tools/chain_lab [launches=64] [reps=50]
+//   tools/chain_lab [launches=64] [reps=50] [s_sleep(127) repetitions between polls=1]      (-DCHAIN_AGENT: sc1 instead of sc0 sc1)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -235,7 +235,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&qw, (size_t)s.K * s.N / 2)); CK(hipMalloc(&qz, (size_t)(s.K / 128) * s.N / 2)); CK(hipMalloc(&sc, (size_t)(s.K / 128) * s.N * 2));
     std::vector<uint32_t> h((size_t)s.K * s.N / 8);
     std::vector<uint16_t> hs((size_t)(s.K / 128) * s.N);
-    const float scale = s.K == 4096 ? 0.0034f : 0.0020f;        // keeps |y| ~ |x| along the chain
+    const float scale = s.K == 4096 ? 0.0024f : 0.00139f;      // 1 / (sqrt(K) * std(q - z) = 6.5): keeps |y| ~ |x| along the chain
     for (auto& v : hs) { _Float16 f = (_Float16)(scale * (0.8f + 0.4f * (float)((rnd() >> 40) * (1.0 / (1 << 24))))); memcpy(&v, &f, 2); }
     CK(hipMemcpy(sc, hs.data(), hs.size() * 2, hipMemcpyHostToDevice));
     for (int i = 0; i < SETS; ++i) {
