@@ -32,7 +32,8 @@ EXPORTS = (
 # include/awq_aux.h (decode-harness helpers, not part of the operator boundary)
 AUX_EXPORTS = ("awq_aux_add_rmsnorm", "awq_aux_decode_attention", "awq_aux_decode_attention_workspace_bytes",
                "awq_aux_argmax_advance", "awq_aux_silu_mul",
-               "awq_aux_gemv_repacked_fused", "awq_aux_moe_gemv", "awq_aux_moe_gemv_blocks", "awq_aux_moe_align_blocks")
+               "awq_aux_gemv_repacked_fused", "awq_aux_moe_gemv", "awq_aux_moe_gemv_blocks", "awq_aux_moe_align_blocks",
+               "awq_aux_moe_align_blocks_n", "awq_aux_moe_gemm_blocks")
 ABI_VERSION = 2
 
 DTYPE_F16, DTYPE_BF16, DTYPE_F32 = 0, 1, 2
@@ -99,6 +100,10 @@ def _bind(L):
     L.awq_aux_moe_gemv_blocks.restype = ci
     L.awq_aux_moe_align_blocks.argtypes = [vp, i64, i64, vp, vp, i64, vp]
     L.awq_aux_moe_align_blocks.restype = ci
+    L.awq_aux_moe_align_blocks_n.argtypes = [vp, i64, i64, ci, vp, vp, i64, vp]
+    L.awq_aux_moe_align_blocks_n.restype = ci
+    L.awq_aux_moe_gemm_blocks.argtypes = [vp, i64, ci, vp, i64, vp, vp, i64, vp, vp, i64, i64, i64, ci, ci, vp]
+    L.awq_aux_moe_gemm_blocks.restype = ci
     L.awq_aux_argmax_advance.argtypes = [vp, vp, vp, i64, i64, vp]
     L.awq_aux_argmax_advance.restype = ci
     L.awq_aux_silu_mul.argtypes = [vp, vp, i64, i64, vp]

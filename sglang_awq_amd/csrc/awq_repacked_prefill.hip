@@ -45,17 +45,32 @@ __device__ __forceinline__ void dq_stage(DqPipe& p, half2_t z1024, half2_t z64, 
 #endif
 constexpr int kPfThreads = 256;
 
+// AWQ-MoE prefill (MOE = true; awq_aux_moe_gemm_blocks): the rows are (token, expert) pairs grouped by expert into 128-row blocks that
+// never straddle two experts (awq_aux_moe_align_blocks_n, the reference's moe_align_block_size step); a row tile takes its weights from
+// expert block_expert[tile] (expert_stride bytes apart; -1 = unused tile: the workgroup leaves), row r of the tile reads activation
+// row row_map[r] / x_div and writes output row row_map[r] (-1 = padding: read row 0, write nothing), with the fp32 sums multiplied by
+// slot_scale[row_map[r]] before the one rounding (the routed weight, where the reference's fused MoE applies it).  EPI = 1: the
+// column groups alternate gate / up (w13 repacked from interleaved tensors) and act = silu(fp16 gate) * fp16 up is written, N / 2 wide.
+struct PfMoe {
+  const int* row_map;
+  const int* block_expert;
+  const float* slot_scale;
+  long long expert_stride;
+  int x_div;
+};
+
 // NJ = column groups (16 columns) per wave: 4 -> 128 x 256 tiles, 3 -> 128 x 192 tiles, 2 -> 128 x 128 tiles.
 // A launch covers the column groups [cg_base, cg_base + ng_region) of the matrix; the host cuts N into a region of 256-wide
 // tiles that fills whole rounds of the 256 CUs and a remainder of 192-wide tiles, so that 2048 x 11008 costs 2 + 0.75 rounds
 // instead of the 3 that 688 equal tiles pay for 2.69 (launch_gemm_repacked_pipelined).
-template <int NJ>
+template <int NJ, bool MOE = false, int EPI = 0>
 __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(const uint16_t* __restrict__ x, int64_t ldx,
                                                                                 const u32x4_t* __restrict__ qw_r,
                                                                                 const uint32_t* __restrict__ zs_r,
                                                                                 const void* __restrict__ bias, void* __restrict__ y, int M,
                                                                                 int K, int N, int g, int NG, int nbx, int nby, int cg_base,
-                                                                                int ng_region) {
+                                                                                int ng_region, PfMoe moe) {
+  static_assert(!EPI || (MOE && NJ % 2 == 0), "SiLU-mul epilogue: whole (gate, up) pairs per wave");
   extern __shared__ __attribute__((aligned(16))) unsigned char As[];      // 2 x 32 KiB
   constexpr int MI = 8, AL = 8;                     // row tiles per wave; x-tile chunks (16 B) per thread
   const int tid = threadIdx.x, lane = tid & 63;
@@ -69,6 +84,12 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
   const int bm = (logical / nbx) * kPfBM;
   const int cg_tile = cg_base + (logical % nbx) * (4 * NJ) + wn * NJ;       // this wave's first column group
   const int cg_end = cg_base + ng_region < NG ? cg_base + ng_region : NG;
+  if constexpr (MOE) {
+    const int eid = moe.block_expert[bm / kPfBM];                  // uniform over the workgroup, read before any barrier
+    if (eid < 0) return;
+    qw_r = (const u32x4_t*)((const unsigned char*)qw_r + (long long)eid * moe.expert_stride);
+    zs_r = (const uint32_t*)((const unsigned char*)zs_r + (long long)eid * moe.expert_stride);
+  }
 
   // Every global load of the loop is a buffer load: SGPR descriptor + 32-bit lane offset + scalar offset (k-block, group), so the
   // k-block's addresses cost a few SALU ops instead of ~60 64-bit VALU ops per k-block in front of the first MFMA.
@@ -83,7 +104,7 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
     zoff_s[j] = (uint32_t)cgj * (uint32_t)groups * 64u;
   }
   const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)zs_r, 0, 0x7fffffff, kRsrcFlags);
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)bm * ldx), 0, 0x7fffffff, kRsrcFlags);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (MOE ? (size_t)0 : (size_t)bm * ldx)), 0, 0x7fffffff, kRsrcFlags);
   const int lane16 = lane * 16, r4 = r * 4;
 
   u32x4_t a_st[AL];
@@ -97,7 +118,11 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
   for (int i = 0; i < AL; ++i) {
     const int c = tid + kPfThreads * i;
     const int row = c >> 4, chunk = c & 15;
-    const int mr = bm + row < M ? row : M - 1 - bm;
+    int mr = bm + row < M ? row : M - 1 - bm;
+    if constexpr (MOE) {
+      const int pr = moe.row_map[bm + row];
+      mr = pr >= 0 ? pr / moe.x_div : 0;
+    }
     xoff[i] = (uint32_t)((size_t)mr * ldx + chunk * 8) * 2u;
   }
   auto load_a = [&](int kb) {
@@ -214,19 +239,47 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
   }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results must have left the pipe before the (compiler-scheduled) reads below
 
+  if constexpr (MOE) {
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = bm + mi * 16 + 4 * q + i;
-      if (m < M) {
+      for (int i = 0; i < 4; ++i) {
+        const int pr = moe.row_map[bm + mi * 16 + 4 * q + i];
+        if (pr < 0) continue;
+        const float sc = moe.slot_scale ? moe.slot_scale[pr] : 1.f;
+        if constexpr (EPI == 1) {
+          const int I = N / 2;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int n = (cg_tile + j) * 16 + r;
-          if (cg_tile + j < cg_end && n < N) store_output<AWQ_DTYPE_F16>(y, (size_t)m * N + n, acc[mi][j][i], bias, n);
+          for (int j = 0; j < NJ; j += 2) {
+            const int n = ((cg_tile + j) >> 1) * 16 + r;
+            if (cg_tile + j + 1 < cg_end && n < I) {
+              const float xg = (float)(half_t)(acc[mi][j][i] * sc);       // the unfused path rounds gate_up to fp16 first
+              ((half_t*)y)[(size_t)pr * I + n] = (half_t)(xg / (1.f + __expf(-xg))) * (half_t)(acc[mi][j + 1][i] * sc);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int n = (cg_tile + j) * 16 + r;
+            if (cg_tile + j < cg_end && n < N) store_output<AWQ_DTYPE_F16>(y, (size_t)pr * N + n, acc[mi][j][i] * sc, nullptr, n);
+          }
         }
       }
-    }
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = bm + mi * 16 + 4 * q + i;
+        if (m < M) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int n = (cg_tile + j) * 16 + r;
+            if (cg_tile + j < cg_end && n < N) store_output<AWQ_DTYPE_F16>(y, (size_t)m * N + n, acc[mi][j][i], bias, n);
+          }
+        }
+      }
+  }
 }
 
 template <int NJ>
@@ -236,8 +289,31 @@ static int pf_launch_region(const GemmArgs& a, const u32x4_t* qw_r, const uint32
   static unsigned long long opted[2] = {0ull, 0ull};
   if (!opt_in_dynamic_lds((const void*)gemm_repacked_pipelined_kernel<NJ>, (int)lds, opted)) return AWQ_ERR_LAUNCH;
   hipLaunchKernelGGL(gemm_repacked_pipelined_kernel<NJ>, dim3(nbx * nby), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r,
-                     zs_r, a.bias, a.y, a.M, a.K, a.N, a.g, NG, nbx, nby, cg_base, ng_region);
+                     zs_r, a.bias, a.y, a.M, a.K, a.N, a.g, NG, nbx, nby, cg_base, ng_region, PfMoe{nullptr, nullptr, nullptr, 0ll, 1});
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
+
+// AWQ-MoE over expert-sorted 128-row blocks: `num_blocks` row tiles x ceil(NG / 16) column tiles of 256 (the remainder tile is clamped)
+template <int EPI>
+static int pf_launch_moe(const GemmArgs& a, const u32x4_t* qw_r, const uint32_t* zs_r, int NG, int num_blocks, const PfMoe& moe) {
+  const int nbx = (NG + 15) / 16, nby = num_blocks;
+  const size_t lds = 2 * kPfBM * 256;
+  static unsigned long long opted[2] = {0ull, 0ull};
+  if (!opt_in_dynamic_lds((const void*)gemm_repacked_pipelined_kernel<4, true, EPI>, (int)lds, opted)) return AWQ_ERR_LAUNCH;
+  hipLaunchKernelGGL((gemm_repacked_pipelined_kernel<4, true, EPI>), dim3(nbx * nby), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x, a.ldx,
+                     qw_r, zs_r, nullptr, a.y, num_blocks * kPfBM, a.K, a.N, a.g, NG, nbx, nby, 0, NG, moe);
+  return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
+
+int launch_gemm_repacked_moe_tiles(const GemmArgs& a, const void* packed_experts, const int* row_map, const int* block_expert, int num_blocks,
+                                   const float* slot_scale, long long expert_stride, int x_div, bool silu_mul) {
+  if (!pipelined_addressable(a)) return AWQ_ERR_BAD_VARIANT;
+  const int NG = rp_groups(a.N);
+  if (silu_mul && (NG & 1)) return AWQ_ERR_BAD_VARIANT;
+  const u32x4_t* qw_r = (const u32x4_t*)packed_experts;
+  const uint32_t* zs_r = (const uint32_t*)packed_experts + (size_t)NG * (a.K / 128) * 256;
+  const PfMoe moe = {row_map, block_expert, slot_scale, expert_stride, x_div};
+  return silu_mul ? pf_launch_moe<1>(a, qw_r, zs_r, NG, num_blocks, moe) : pf_launch_moe<0>(a, qw_r, zs_r, NG, num_blocks, moe);
 }
 
 // 32-bit offsets inside the kernel's buffer descriptors: a 128-row x tile, the scale words and one column group's strip of weights

@@ -14,7 +14,7 @@ every expert gets the MFMA-fragment-major copy of the dense path (`awq_repack` r
 column-interleaved tensors so SiLU·mul is the GEMV's epilogue), and a forward is, without any host synchronisation
 (graph-capturable at every size):
 
-    few pairs (tokens x top_k <= MOE_SLOT_MAX_PAIRS): two launches of `awq_aux_moe_gemv` over the (token, expert) pairs, one
+    few pairs (tokens x top_k <= max(MOE_SLOT_MAX_PAIRS, E / 2)): two launches of `awq_aux_moe_gemv` over the (token, expert) pairs, one
         grid row per pair — w13 with the SiLU·mul epilogue, w2 with the routed weight applied to the fp32 sums;
     more pairs: the pairs are sorted by expert ON THE DEVICE and cut into 16-row blocks that never straddle two experts (the
         reference's moe_align_block_size step), then two launches of `awq_aux_moe_gemv_blocks` — one expert stream per 16 rows
@@ -66,6 +66,18 @@ class AWQMoEMethod:
     # for up to 16 rows per expert: they cross near 13 pairs
     MOE_SLOT_MAX_PAIRS = 12
     MOE_GEMV_MAX_SLOTS = MOE_SLOT_MAX_PAIRS   # (name of rounds 1-2)
+
+    # average rows per expert from which the 128-row tile route (MFMA tile kernel) replaces the 16-row block route
+    TILE_ROUTE_MIN_ROWS_PER_EXPERT = 24
+
+    @classmethod
+    def slot_route_max_pairs(cls, num_experts: int) -> int:
+        """Most (token, expert) pairs the slot route serves for a layer of `num_experts` experts.  With many experts a batch's pairs mostly
+        hit DIFFERENT experts (up to E / 2 pairs at least 79 % of them are distinct in expectation), so grouping them saves little
+        traffic and the slot route's one-row stream is faster per byte.  Measured on DeepSeek-V3-like routed experts (E = 256,
+        K = 7168, I = 2048, top-8; profiles/r03_time_moe_deepseek_v3_shapes.txt): 16 / 32 / 64 / 128 pairs 89 / 165 / 298 / 568 us
+        against 138 / 231 / 384 / 620 on the block route; 256 / 512 pairs 1112 / 2203 against 969 / 1330."""
+        return max(cls.MOE_SLOT_MAX_PAIRS, int(num_experts) // 2)
 
     def __init__(self, quant_config: AWQConfig):
         if quant_config.weight_bits != 4:
@@ -138,11 +150,12 @@ class AWQMoEMethod:
         _lib.check(rc, "awq_aux_moe_gemv")
         return y
 
-    def _moe_blocks(self, x, packed, row_map, block_expert, slot_scale, pairs, x_div, K, N, silu):
+    def _moe_blocks(self, x, packed, row_map, block_expert, slot_scale, pairs, x_div, K, N, silu, tiles=False):
         g = self.quant_config.group_size
         # rows of padded / dropped pairs are never written by the kernel: start from zeros so the top_k sum ignores them
         y = torch.zeros((pairs, N // 2 if silu else N), dtype=torch.float16, device=x.device)
-        rc = _lib.load().awq_aux_moe_gemv_blocks(ctypes.c_void_p(x.data_ptr()), x.stride(0), int(x_div), ctypes.c_void_p(packed.data_ptr()),
+        fn = _lib.load().awq_aux_moe_gemm_blocks if tiles else _lib.load().awq_aux_moe_gemv_blocks     # 128-row / 16-row blocks
+        rc = fn(ctypes.c_void_p(x.data_ptr()), x.stride(0), int(x_div), ctypes.c_void_p(packed.data_ptr()),
                                                  packed.stride(0), ctypes.c_void_p(row_map.data_ptr()),
                                                  ctypes.c_void_p(block_expert.data_ptr()), block_expert.numel(),
                                                  ctypes.c_void_p(slot_scale.data_ptr()) if slot_scale is not None else None,
@@ -150,7 +163,7 @@ class AWQMoEMethod:
                                                  ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
         if rc == _lib.ERR_BAD_VARIANT:
             return None
-        _lib.check(rc, "awq_aux_moe_gemv_blocks")
+        _lib.check(rc, "awq_aux_moe_gemm_blocks" if tiles else "awq_aux_moe_gemv_blocks")
         return y
 
     @staticmethod
@@ -184,20 +197,20 @@ class AWQMoEMethod:
         return row_map, block_expert
 
     @classmethod
-    def align_blocks_device(cls, ids: torch.Tensor, num_experts: int):
+    def align_blocks_device(cls, ids: torch.Tensor, num_experts: int, block: int = 16):
         """align_blocks as one small launch (`awq_aux_moe_align_blocks`: counting sort through LDS, one workgroup) instead of a dozen
         tensor ops (~100 us of launch boundaries per MoE layer, profiles/r03_time_moe.txt); the same contract except that the order of
         the rows inside an expert's run is not specified.  More than 1024 experts: the tensor-op form."""
         if not ids.is_cuda or num_experts > 1024:
-            return cls.align_blocks(ids, num_experts)
+            return cls.align_blocks(ids, num_experts, block)
         P = ids.numel()
-        B = (P + 15) // 16 + num_experts
-        row_map = torch.empty(B * 16, dtype=torch.int32, device=ids.device)
+        B = (P + block - 1) // block + num_experts
+        row_map = torch.empty(B * block, dtype=torch.int32, device=ids.device)
         block_expert = torch.empty(B, dtype=torch.int32, device=ids.device)
-        rc = _lib.load().awq_aux_moe_align_blocks(ctypes.c_void_p(ids.data_ptr()), P, num_experts, ctypes.c_void_p(row_map.data_ptr()),
-                                                  ctypes.c_void_p(block_expert.data_ptr()), B,
-                                                  ctypes.c_void_p(torch.cuda.current_stream(ids.device).cuda_stream))
-        _lib.check(rc, "awq_aux_moe_align_blocks")
+        rc = _lib.load().awq_aux_moe_align_blocks_n(ctypes.c_void_p(ids.data_ptr()), P, num_experts, int(block),
+                                                    ctypes.c_void_p(row_map.data_ptr()), ctypes.c_void_p(block_expert.data_ptr()), B,
+                                                    ctypes.c_void_p(torch.cuda.current_stream(ids.device).cuda_stream))
+        _lib.check(rc, "awq_aux_moe_align_blocks_n")
         return row_map, block_expert
 
     def apply(self, layer: torch.nn.Module, dispatch_output, topk_weights: Optional[torch.Tensor] = None,
@@ -231,10 +244,16 @@ class AWQMoEMethod:
         wts = topk_weights.to(torch.float32).contiguous().view(-1)
         pairs = T * top_k
         y = None
-        if pairs <= self.MOE_SLOT_MAX_PAIRS:
+        if pairs <= self.slot_route_max_pairs(E):
             act = self._moe_gemv(x, layer.w13_packed, ids, None, pairs, top_k, K, 2 * I, True, E)
             if act is not None:
                 y = self._moe_gemv(act, layer.w2_packed, ids, wts, pairs, 1, I, K, False, E)
+        if y is None and pairs >= self.TILE_ROUTE_MIN_ROWS_PER_EXPERT * E:
+            # prefill-sized batch: 128-row blocks on the MFMA tile kernel (each active expert streamed once per 128 of its rows)
+            row_map, block_expert = self.align_blocks_device(ids, E, 128)
+            act = self._moe_blocks(x, layer.w13_packed, row_map, block_expert, None, pairs, top_k, K, 2 * I, True, tiles=True)
+            if act is not None:
+                y = self._moe_blocks(act, layer.w2_packed, row_map, block_expert, wts, pairs, 1, I, K, False, tiles=True)
         if y is None:
             row_map, block_expert = self.align_blocks_device(ids, E)
             act = self._moe_blocks(x, layer.w13_packed, row_map, block_expert, None, pairs, top_k, K, 2 * I, True)

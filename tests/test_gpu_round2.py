@@ -355,6 +355,8 @@ def test_awq_moe_method_vs_oracle(ops, T):
 
     want = np.zeros((T, K))
     scale = np.zeros((T, K))
+    terms = np.zeros((T, K))
+    absw2 = [np.abs(c_oracle.dequantize(*w2[e]).astype(np.float32)) for e in range(E)]
     for t in range(T):
         for k in range(top_k):
             e = int(ti_np[t, k])
@@ -366,12 +368,16 @@ def test_awq_moe_method_vs_oracle(ops, T):
             ys = (tw_np[t, k] * y[0]).astype(np.float16).astype(np.float64)
             want[t] += ys
             scale[t] += np.abs(ys)
+            terms[t] += tw_np[t, k] * (np.abs(act.astype(np.float32)) @ absw2[e])[0]      # sum_i |act_i W2[i, n]|: what a flipped act ulp acts on
     want = want.astype(np.float16).astype(np.float64)
-    # the kernel's silu (__expf) may land on a neighbouring half for some act elements, which moves a w2 sum by a few 1e-4
-    # relative; each slot and the final sum round once more
-    tol = 2.5 * (2.0 ** (np.floor(np.log2(np.maximum(scale, 2.0 ** -14))) - 10)) + 2e-3 * (1.0 + scale)
+    # the kernel's silu (__expf) and its fp32 gate sums (summation order differs per route) may land some act elements on a
+    # neighbouring half: one fp16 ulp (2^-11 relative) of a share of the w2 terms — bounded through sum_i |act_i W2[i, n]|, which a
+    # cancelling w2 sum can be far below; each slot and the final sum round once more
+    tol = 2.5 * (2.0 ** (np.floor(np.log2(np.maximum(scale, 2.0 ** -14))) - 10)) + 2e-3 * (1.0 + scale) + 2.0 ** -13 * terms
     err = np.abs(out - want)
-    assert np.all(err <= tol), f"T={T}: worst {err.max():.3e} at scale {scale.flat[err.argmax()]:.3f}"
+    worst = int((err / tol).argmax())
+    assert np.all(err <= tol), (f"T={T}: {int((err > tol).sum())} of {err.size} outside; worst err {err.flat[worst]:.3e} (tolerance {tol.flat[worst]:.3e}) "
+                                f"at scale {scale.flat[worst]:.3f}, element {np.unravel_index(worst, err.shape)}, got {out.flat[worst]:.5f} want {want.flat[worst]:.5f}")
     # every route applies the routed weight to the fp32 sums before the one rounding (slot route up to MOE_SLOT_MAX_PAIRS pairs,
     # expert-sorted 16-row blocks beyond): the same share of one-ulp differences on both
     assert float((out != want).mean()) < 0.25

@@ -123,14 +123,14 @@ def test_moe_block_route_matches_slot_route(ops):
     T = 4
     x = to_torch(synth.make_activations(T, K, "f16", "A", seed=3, x_std=0.5), DEV)
     tw, ti = select_experts(to_torch(synth.make_activations(T, E, "f16", "A", seed=4).astype(np.float32), DEV), top_k)
-    assert T * top_k <= AWQMoEMethod.MOE_SLOT_MAX_PAIRS
+    assert T * top_k <= AWQMoEMethod.slot_route_max_pairs(E)
     y_slot = method.apply(layer, x, tw, ti)
-    saved = AWQMoEMethod.MOE_SLOT_MAX_PAIRS
+    saved = AWQMoEMethod.__dict__["slot_route_max_pairs"]
     try:
-        AWQMoEMethod.MOE_SLOT_MAX_PAIRS = 0
+        AWQMoEMethod.slot_route_max_pairs = classmethod(lambda cls, num_experts: 0)
         y_blk = method.apply(layer, x, tw, ti)
     finally:
-        AWQMoEMethod.MOE_SLOT_MAX_PAIRS = saved
+        AWQMoEMethod.slot_route_max_pairs = saved
     # (same arithmetic; hipcc may fuse `fp16(sum * routed_weight)` into one v_fma_mixlo_f16 — a single rounding of the exact product —
     # in one kernel and keep the fp32 multiply + conversion in the other: a rare one-ulp double-rounding difference, nothing else)
     diff = y_slot != y_blk
@@ -399,27 +399,29 @@ def test_7b_dimension_layers_match_fp32_reference(B):
     assert "folded" in model.layers[0].norm_order(B) if B <= 16 else "reference" in model.layers[0].norm_order(B)
 
 
+@pytest.mark.parametrize("BS", [16, 128])
 @pytest.mark.parametrize("P,E", [(1, 8), (40, 8), (600, 8), (33, 4), (5, 1), (4096, 60), (7, 1024)])
-def test_moe_align_blocks_kernel_contract(ops, P, E):
-    """awq_aux_moe_align_blocks (one-workgroup counting sort) against the contract of the tensor-op form: every valid pair exactly once, in a
-    block of its own expert; padding and unused blocks are -1; ids outside [0, E) are dropped; experts in ascending block order."""
+def test_moe_align_blocks_kernel_contract(ops, P, E, BS):
+    """awq_aux_moe_align_blocks_n (one-workgroup counting sort; 16-row blocks for the GEMV route, 128-row blocks for the MFMA tile route)
+    against the contract of the tensor-op form: every valid pair exactly once, in a block of its own expert; padding and unused blocks are
+    -1; ids outside [0, E) are dropped; experts in ascending block order."""
     from sglang_awq_amd.moe import AWQMoEMethod
 
     g = torch.Generator().manual_seed(P * 7 + E)
     ids = torch.randint(-1, E, (P,), dtype=torch.int32, generator=g)
     if P > 3:
         ids[2] = E + 5
-    row_map, block_expert = AWQMoEMethod.align_blocks_device(ids.to(DEV), E)
+    row_map, block_expert = AWQMoEMethod.align_blocks_device(ids.to(DEV), E, BS)
     torch.cuda.synchronize()
     row_map, block_expert = row_map.cpu(), block_expert.cpu()
     B = block_expert.numel()
-    assert B == (P + 15) // 16 + E and row_map.numel() == 16 * B
-    ref_map, ref_be = AWQMoEMethod.align_blocks(ids, E)
+    assert B == (P + BS - 1) // BS + E and row_map.numel() == BS * B
+    ref_map, ref_be = AWQMoEMethod.align_blocks(ids, E, BS)
     assert torch.equal(block_expert, ref_be)
     seen = []
     for b in range(B):
         e = int(block_expert[b])
-        rows = row_map[b * 16:(b + 1) * 16].tolist()
+        rows = row_map[b * BS:(b + 1) * BS].tolist()
         if e < 0:
             assert all(r == -1 for r in rows)
             continue
@@ -427,12 +429,45 @@ def test_moe_align_blocks_kernel_contract(ops, P, E):
         assert real and all(int(ids[r]) == e for r in real)
         seen += real
     assert sorted(seen) == [i for i in range(P) if 0 <= int(ids[i]) < E]
-    for b in range(B):            # the same SET of rows per block region as the stable reference (order inside an expert's run is free)
-        pass
+    # the same SET of rows per expert as the stable reference (the order inside an expert's run is free)
     for e in range(E):
-        got = sorted(r for b in range(B) if int(block_expert[b]) == e for r in row_map[b * 16:(b + 1) * 16].tolist() if r >= 0)
-        want = sorted(r for b in range(B) if int(ref_be[b]) == e for r in ref_map[b * 16:(b + 1) * 16].tolist() if r >= 0)
+        got = sorted(r for b in range(B) if int(block_expert[b]) == e for r in row_map[b * BS:(b + 1) * BS].tolist() if r >= 0)
+        want = sorted(r for b in range(B) if int(ref_be[b]) == e for r in ref_map[b * BS:(b + 1) * BS].tolist() if r >= 0)
         assert got == want
+
+
+def test_moe_tile_route_matches_block_route(ops):
+    """Prefill-sized MoE batches run expert-sorted 128-row blocks on the MFMA tile kernel (awq_aux_moe_gemm_blocks:
+    gemm_repacked_pipelined_kernel<4, MOE>) instead of 16-row blocks on the GEMV (awq_aux_moe_gemv_blocks).  Same rounding points
+    (fp16 gate_up -> silu * up in the epilogue -> routed weight on the fp32 sums -> one rounding); the fp32 summation order differs, so a
+    rounding flips here and there: at most one fp16 ulp of an output's slots.  Padded tokens (ids -1, layers/moe/topk.py:705-712) give zero
+    rows on both routes; ragged expert loads (one expert with a single row, one with none) and a width that is not a multiple of the
+    256-column tile are covered."""
+    from sglang_awq_amd.moe import AWQMoEMethod, select_experts
+
+    E, K, I, top_k, g = 5, 2048, 640, 2, 128             # 2 I = 1280 = 5 tiles of 256; K = 2048 -> w2 width 2048
+    method, layer = _moe_layer(E, K, I, g, seed0=700)
+    T = 200
+    x = to_torch(synth.make_activations(T, K, "f16", "A", seed=31, x_std=0.5), DEV)
+    logits = to_torch(synth.make_activations(T, E, "f16", "A", seed=32).astype(np.float32), DEV)
+    logits[:, 4] = -1e4                                    # expert 4 is never chosen ...
+    tw, ti = select_experts(logits, top_k)
+    ti[7, 1] = 4                                           # ... except by one pair
+    ti[-8:] = -1                                           # padded tokens of a graph batch
+    assert T * top_k >= AWQMoEMethod.TILE_ROUTE_MIN_ROWS_PER_EXPERT * E
+    y_tile = method.apply(layer, x, tw, ti)
+    saved = AWQMoEMethod.TILE_ROUTE_MIN_ROWS_PER_EXPERT
+    try:
+        AWQMoEMethod.TILE_ROUTE_MIN_ROWS_PER_EXPERT = 1e18
+        y_blk = method.apply(layer, x, tw, ti)
+    finally:
+        AWQMoEMethod.TILE_ROUTE_MIN_ROWS_PER_EXPERT = saved
+    assert torch.isfinite(y_tile).all() and torch.count_nonzero(y_tile[-8:]) == 0 and torch.count_nonzero(y_blk[-8:]) == 0
+    d = (y_tile.float() - y_blk.float()).abs()
+    ulp = 2.0 ** (torch.floor(torch.log2(y_blk.float().abs().clamp_min(2.0 ** -14))) - 10)
+    # an act element landing on the neighbouring half moves a w2 sum slightly; then one rounding per slot and one of the top_k sum
+    assert (d <= 4 * ulp + 4e-3).all(), f"worst {d.max().item()} at |y| {y_blk.float().abs().flatten()[d.argmax()].item()}"
+    assert float((y_tile != y_blk).float().mean()) < 0.25
 
 
 def test_split_s_attention_same_workspace_across_batch_sizes():

@@ -67,3 +67,13 @@ def test_create_weights_shapes_match_the_reference():
     assert callable(layer.w13_qweight.weight_loader)
     with pytest.raises(ValueError):
         AWQMoEMethod(AWQConfig(4, 128, True)).create_weights(torch.nn.Module(), 2, 200, 512, torch.float16)
+
+
+def test_slot_route_threshold_grows_with_expert_count():
+    """Few experts: pairs beyond 12 share experts, grouping them pays (Mixtral-like); many experts: up to E / 2 pairs mostly hit
+    different experts and stay on the one-row-per-pair route (DeepSeek-V3-like, measured in profiles/r03_time_moe_deepseek_v3_shapes.txt)."""
+    from sglang_awq_amd.moe import AWQMoEMethod
+
+    assert AWQMoEMethod.slot_route_max_pairs(8) == 12
+    assert AWQMoEMethod.slot_route_max_pairs(64) == 32
+    assert AWQMoEMethod.slot_route_max_pairs(256) == 128
