@@ -83,13 +83,13 @@ int awq_aux_moe_gemv_blocks(const void* x, int64_t ldx, int x_div, const void* p
 /* Prefill-sized batches (tens of rows per expert and more): the same two steps with blocks of 128 rows on the MFMA tile kernel of the
  * dense prefill path (128 x 256 tiles; the reference's fused MoE kernels run block_m 64..128 there,
  * layers/moe/fused_moe_triton/fused_moe.py) — each active expert is streamed once per 128 of its rows instead of once per 16.
- * awq_aux_moe_align_blocks_n: block_rows in {16, 128}; row_map [block_rows * num_blocks], num_blocks >= ceil(pairs / block_rows) +
- * num_experts.  awq_aux_moe_gemm_blocks: same arguments and rounding points as awq_aux_moe_gemv_blocks over 128-row blocks
- * (silu_mul: N / 16 even). */
+ * awq_aux_moe_align_blocks_n: block_rows in {16, 64, 128}; row_map [block_rows * num_blocks], num_blocks >= ceil(pairs / block_rows) +
+ * num_experts.  awq_aux_moe_gemm_blocks: same arguments and rounding points as awq_aux_moe_gemv_blocks over blocks of block_rows =
+ * 128 or 64 rows (64: layers of many thinly loaded experts — half the MFMA work per streamed weight; silu_mul: N / 16 even). */
 int awq_aux_moe_align_blocks_n(const int32_t* ids, int64_t pairs, int64_t num_experts, int block_rows, int32_t* row_map,
                                int32_t* block_expert, int64_t num_blocks, void* stream);
 int awq_aux_moe_gemm_blocks(const void* x, int64_t ldx, int x_div, const void* packed_experts, int64_t expert_stride_bytes,
-                            const int32_t* row_map, const int32_t* block_expert, int64_t num_blocks, const float* slot_scale,
+                            const int32_t* row_map, const int32_t* block_expert, int64_t num_blocks, int block_rows, const float* slot_scale,
                             void* y, int64_t K, int64_t N, int64_t group_size, int dtype, int silu_mul, void* stream);
 
 #ifdef __cplusplus

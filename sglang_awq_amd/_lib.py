@@ -102,7 +102,7 @@ def _bind(L):
     L.awq_aux_moe_align_blocks.restype = ci
     L.awq_aux_moe_align_blocks_n.argtypes = [vp, i64, i64, ci, vp, vp, i64, vp]
     L.awq_aux_moe_align_blocks_n.restype = ci
-    L.awq_aux_moe_gemm_blocks.argtypes = [vp, i64, ci, vp, i64, vp, vp, i64, vp, vp, i64, i64, i64, ci, ci, vp]
+    L.awq_aux_moe_gemm_blocks.argtypes = [vp, i64, ci, vp, i64, vp, vp, i64, ci, vp, vp, i64, i64, i64, ci, ci, vp]
     L.awq_aux_moe_gemm_blocks.restype = ci
     L.awq_aux_argmax_advance.argtypes = [vp, vp, vp, i64, i64, vp]
     L.awq_aux_argmax_advance.restype = ci

@@ -89,7 +89,7 @@ int launch_gemm_repacked_ksplit(const GemmArgs& a, const void* packed);      // 
 int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed);   // its hand-pipelined 128 x 256 form (awq_repacked_prefill.hip)
 // the same kernel over expert-sorted 128-row blocks of (token, expert) pairs (AWQ-MoE prefill; awq_aux_moe_gemm_blocks)
 int launch_gemm_repacked_moe_tiles(const GemmArgs& a, const void* packed_experts, const int* row_map, const int* block_expert, int num_blocks,
-                                   const float* slot_scale, long long expert_stride, int x_div, bool silu_mul);
+                                   int block_rows, const float* slot_scale, long long expert_stride, int x_div, bool silu_mul);
 
 // Opt a kernel in to more than 64 KiB of dynamic LDS on the CURRENT device.  The attribute belongs to the function object of
 // a device, and the shim serves several devices from one process: remember per (kernel, device) instead of once per process.

@@ -376,13 +376,13 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const int* __restrict__
 extern "C" int awq_aux_moe_align_blocks_n(const int32_t* ids, int64_t pairs, int64_t num_experts, int block_rows, int32_t* row_map,
                                           int32_t* block_expert, int64_t num_blocks, void* stream) {
   if (!ids || !row_map || !block_expert) return AWQ_ERR_NULL_POINTER;
-  if (block_rows != 16 && block_rows != 128) return AWQ_ERR_BAD_SHAPE;
+  if (block_rows != 16 && block_rows != 64 && block_rows != 128) return AWQ_ERR_BAD_SHAPE;
   if (pairs <= 0 || num_experts < 1 || num_blocks < (pairs + block_rows - 1) / block_rows + num_experts || num_blocks > (1 << 24) || pairs > (1 << 28) ||
       num_blocks * block_rows >= (int64_t(1) << 31))
     return AWQ_ERR_BAD_SHAPE;
   if (num_experts > awq::kAlignMaxExperts) return AWQ_ERR_BAD_VARIANT;
   hipLaunchKernelGGL(awq::moe_align_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ids, (int)pairs, (int)num_experts, row_map,
-                     block_expert, (int)num_blocks, block_rows == 16 ? 4 : 7);
+                     block_expert, (int)num_blocks, block_rows == 16 ? 4 : block_rows == 64 ? 6 : 7);
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
@@ -393,25 +393,26 @@ extern "C" int awq_aux_moe_align_blocks(const int32_t* ids, int64_t pairs, int64
 
 // AWQ-MoE over expert-sorted pairs in blocks of 128 rows on the MFMA tile kernel (include/awq_aux.h; awq_repacked_prefill.hip)
 extern "C" int awq_aux_moe_gemm_blocks(const void* x, int64_t ldx, int x_div, const void* packed_experts, int64_t expert_stride_bytes,
-                                       const int32_t* row_map, const int32_t* block_expert, int64_t num_blocks, const float* slot_scale,
+                                       const int32_t* row_map, const int32_t* block_expert, int64_t num_blocks, int block_rows, const float* slot_scale,
                                        void* y, int64_t K, int64_t N, int64_t group_size, int dtype, int silu_mul, void* stream) {
   using namespace awq;
   if (!x || !packed_experts || !row_map || !block_expert || !y) return AWQ_ERR_NULL_POINTER;
-  if (K <= 0 || N <= 0 || group_size <= 0 || N % 8 || K % group_size || num_blocks <= 0 || num_blocks > (1 << 20) || ldx < K || x_div < 1)
+  if (K <= 0 || N <= 0 || group_size <= 0 || N % 8 || K % group_size || num_blocks <= 0 || num_blocks > (1 << 20) || ldx < K || x_div < 1 ||
+      (block_rows != 64 && block_rows != 128))
     return AWQ_ERR_BAD_SHAPE;
   if ((((uintptr_t)packed_experts) & 15) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 1) || (expert_stride_bytes & 15) || ldx % 8)
     return AWQ_ERR_MISALIGNED;
   if (!repacked_fast(K, N, group_size, dtype) || (silu_mul && N % 32)) return AWQ_ERR_BAD_VARIANT;
-  if ((num_blocks * 128 / x_div + 1) * ldx >= (int64_t(1) << 31)) return AWQ_ERR_BAD_VARIANT;     // 32-bit activation row offsets in the kernel
+  if ((num_blocks * block_rows / x_div + 1) * ldx >= (int64_t(1) << 31)) return AWQ_ERR_BAD_VARIANT;     // 32-bit activation row offsets in the kernel
   const int64_t tiles = num_blocks * ((rp_groups(N) + 15) / 16);
   if (tiles >= (int64_t(1) << 31)) return AWQ_ERR_BAD_VARIANT;
   GemmArgs a;
   a.x = x; a.ldx = ldx; a.qweight = nullptr; a.scales = nullptr; a.qzeros = nullptr; a.bias = nullptr; a.y = y;
   a.workspace = nullptr; a.workspace_bytes = 0;
-  a.M = (int)(num_blocks * 128); a.K = (int)K; a.N = (int)N; a.g = (int)group_size; a.dtype = dtype; a.tune = 0;
+  a.M = (int)(num_blocks * block_rows); a.K = (int)K; a.N = (int)N; a.g = (int)group_size; a.dtype = dtype; a.tune = 0;
   a.stream = (hipStream_t)stream;
-  return launch_gemm_repacked_moe_tiles(a, packed_experts, row_map, block_expert, (int)num_blocks, slot_scale, (long long)expert_stride_bytes,
-                                        x_div, silu_mul != 0);
+  return launch_gemm_repacked_moe_tiles(a, packed_experts, row_map, block_expert, (int)num_blocks, block_rows, slot_scale,
+                                        (long long)expert_stride_bytes, x_div, silu_mul != 0);
 }
 
 // AWQ-MoE over expert-sorted (token, expert) pairs in blocks of 16 rows (include/awq_aux.h).

@@ -63,7 +63,7 @@ struct PfMoe {
 // A launch covers the column groups [cg_base, cg_base + ng_region) of the matrix; the host cuts N into a region of 256-wide
 // tiles that fills whole rounds of the 256 CUs and a remainder of 192-wide tiles, so that 2048 x 11008 costs 2 + 0.75 rounds
 // instead of the 3 that 688 equal tiles pay for 2.69 (launch_gemm_repacked_pipelined).
-template <int NJ, bool MOE = false, int EPI = 0>
+template <int NJ, bool MOE = false, int EPI = 0, int MI = 8>
 __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(const uint16_t* __restrict__ x, int64_t ldx,
                                                                                 const u32x4_t* __restrict__ qw_r,
                                                                                 const uint32_t* __restrict__ zs_r,
@@ -71,8 +71,11 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
                                                                                 int K, int N, int g, int NG, int nbx, int nby, int cg_base,
                                                                                 int ng_region, PfMoe moe) {
   static_assert(!EPI || (MOE && NJ % 2 == 0), "SiLU-mul epilogue: whole (gate, up) pairs per wave");
+  static_assert(MI == 8 || MI == 4, "128- or 64-row tiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char As[];      // 2 x 32 KiB
-  constexpr int MI = 8, AL = 8;                     // row tiles per wave; x-tile chunks (16 B) per thread
+  // MI = row tiles (16 rows) per wave: 8 -> 128-row workgroup tiles; 4 -> 64-row tiles (MoE layers whose experts hold ~64 rows each:
+  // half the MFMA work per streamed weight, the 7 dequantise stages two to an MFMA slot instead of one)
+  constexpr int BM = MI * 16, AL = MI;              // rows per workgroup tile; x-tile chunks (16 B) per thread
   const int tid = threadIdx.x, lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform on purpose: every weight / scale address below is
   const int q = lane >> 4, r = lane & 15;                          // an SGPR base + a 32-bit lane offset (no 64-bit VALU address math
@@ -81,11 +84,11 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
   const int nwg = nbx * nby, bid = blockIdx.x;
   const int xcd = bid & 7, qd = nwg >> 3, rem = nwg & 7;
   const int logical = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (bid >> 3);
-  const int bm = (logical / nbx) * kPfBM;
+  const int bm = (logical / nbx) * BM;
   const int cg_tile = cg_base + (logical % nbx) * (4 * NJ) + wn * NJ;       // this wave's first column group
   const int cg_end = cg_base + ng_region < NG ? cg_base + ng_region : NG;
   if constexpr (MOE) {
-    const int eid = moe.block_expert[bm / kPfBM];                  // uniform over the workgroup, read before any barrier
+    const int eid = moe.block_expert[bm / BM];                  // uniform over the workgroup, read before any barrier
     if (eid < 0) return;
     qw_r = (const u32x4_t*)((const unsigned char*)qw_r + (long long)eid * moe.expert_stride);
     zs_r = (const uint32_t*)((const unsigned char*)zs_r + (long long)eid * moe.expert_stride);
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
   };
   auto store_a1 = [&](int buf, int i) {
     const int c = tid + kPfThreads * i;
-    *(u32x4_t*)(As + buf * (kPfBM * 256) + pfp_off(c >> 4, c & 15)) = a_st[i];
+    *(u32x4_t*)(As + buf * (BM * 256) + pfp_off(c >> 4, c & 15)) = a_st[i];
   };
   auto load_b = [&](u32x4_t (&w)[NJ], uint32_t (&zs)[NJ], int kb, int grp) {
 #pragma unroll
@@ -168,9 +171,9 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
   // in the shadow of the remaining MFMAs — no LDS latency is exposed at the block boundary.
   for (int kb = 0; kb < KB; ++kb) {
     const int nxt = kb + 1 < KB ? kb + 1 : kb;         // clamped, unconditional prefetch (no branch between load and use)
-    const unsigned char* Ab = As + (kb & 1) * (kPfBM * 256);
+    const unsigned char* Ab = As + (kb & 1) * (BM * 256);
     const int nbuf = (kb + 1) & 1;
-    const unsigned char* An = As + nbuf * (kPfBM * 256);
+    const unsigned char* An = As + nbuf * (BM * 256);
     const int nx2 = kb + 2 < KB ? kb + 2 : KB - 1;
     if (kb + 1 < KB && ++cnt_n == kpg) { cnt_n = 0; ++grp_n; }
     load_b(w_nxt, zs_nxt, nxt, grp_n);
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
           mfma_tied(acc[mi][j], af[mi], frag);
-          if constexpr (!(PF_ABL & 1)) switch (mi) {      // (compile-time after unrolling)
+          if constexpr (!(PF_ABL & 1) && MI == 8) switch (mi) {      // (compile-time after unrolling)
             case 0: dq_stage<0>(p, zn.z1024, zn.z64, zn.s2); break;
             case 1: dq_stage<1>(p, zn.z1024, zn.z64, zn.s2); break;
             case 2: dq_stage<2>(p, zn.z1024, zn.z64, zn.s2); break;
@@ -198,6 +201,12 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
             case 5: dq_stage<5>(p, zn.z1024, zn.z64, zn.s2); break;
             case 6: dq_stage<6>(p, zn.z1024, zn.z64, zn.s2); break;
             default: break;
+          }
+          if constexpr (!(PF_ABL & 1) && MI == 4) switch (mi) {
+            case 0: dq_stage<0>(p, zn.z1024, zn.z64, zn.s2); dq_stage<1>(p, zn.z1024, zn.z64, zn.s2); break;
+            case 1: dq_stage<2>(p, zn.z1024, zn.z64, zn.s2); dq_stage<3>(p, zn.z1024, zn.z64, zn.s2); break;
+            case 2: dq_stage<4>(p, zn.z1024, zn.z64, zn.s2); dq_stage<5>(p, zn.z1024, zn.z64, zn.s2); break;
+            default: dq_stage<6>(p, zn.z1024, zn.z64, zn.s2); break;
           }
           // passengers of the free slots
           // (read in the order 7 .. 0: the first consumer, row tile 0, then waits for the youngest read, and the compiler emits one
@@ -208,23 +217,23 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
           // row of tiles ask for the same fresh lines together, so they take about a k-block to arrive
           if constexpr (NJ == 4) {
             if (!(PF_ABL & 4) && ((d == 1 && j >= 2) || (d == 2 && j <= 1)) && (mi & 3) == 0)
-              store_a1(nbuf, AL - 1 - (((d - 1) * 4 + j - 2) * 2 + (mi >> 2)));
+              store_a1(nbuf, AL - 1 - (((d - 1) * 4 + j - 2) * (MI / 4) + (mi >> 2)));
             if (!(PF_ABL & 4) && d == 2 && j == 2 && mi == 0) load_a(nx2);
-            if (d == 2 && j == 3 && mi == 7) { pin_here(zs_nxt[0]); zu_nxt[0] = zs_unpack(zs_nxt[0]); }
+            if (d == 2 && j == 3 && mi == MI - 1) { pin_here(zs_nxt[0]); zu_nxt[0] = zs_unpack(zs_nxt[0]); }
           } else {
             // three fragments per k-step: the eight writes ride in (d, j) = (1, 2), (2, 0), (2, 2) behind MFMAs 0, 3, 6 (the j = 1
             // slots carry the fragment reads), the next tile is requested behind the last of them
             // (two per k-step: four writes each in (1, 0) and (2, 0), behind every second MFMA)
             const int slot = NJ == 3 ? ((d == 1 && j == 2) ? 0 : (d == 2 && j == 0) ? 1 : (d == 2 && j == 2) ? 2 : -1)
                                      : ((d == 1 && j == 0) ? 0 : (d == 2 && j == 0) ? 1 : -1);     // (compile-time after unrolling)
-            constexpr int PER = NJ == 3 ? 3 : 2, CNT = NJ == 3 ? 3 : 4;
+            constexpr int PER = NJ == 3 ? 3 : 2, CNT = (MI + PER - 1) / PER;
             if (!(PF_ABL & 4) && slot >= 0 && mi % PER == 0 && slot * CNT + mi / PER < AL) store_a1(nbuf, AL - 1 - (slot * CNT + mi / PER));
-            if (!(PF_ABL & 4) && d == 2 && j == NJ - 1 && mi == 7) load_a(nx2);
-            if (d == 2 && j == 1 && mi == 7) { pin_here(zs_nxt[0]); zu_nxt[0] = zs_unpack(zs_nxt[0]); }
+            if (!(PF_ABL & 4) && d == 2 && j == NJ - 1 && mi == MI - 1) load_a(nx2);
+            if (d == 2 && j == 1 && mi == MI - 1) { pin_here(zs_nxt[0]); zu_nxt[0] = zs_unpack(zs_nxt[0]); }
           }
           if (!(PF_ABL & 8) && d == 3 && j == 0 && mi == 0) __syncthreads();
           if (!(PF_ABL & 2) && d == 3 && j == 1) af_n[MI - 1 - mi] = *(const u32x4_t*)(An + pfp_off((MI - 1 - mi) * 16 + r, q));    // next k-block's first fragments
-          if (d == 3 && j < NJ - 1 && mi == 7) { pin_here(zs_nxt[j + 1]); zu_nxt[j + 1] = zs_unpack(zs_nxt[j + 1]); }
+          if (d == 3 && j < NJ - 1 && mi == MI - 1) { pin_here(zs_nxt[j + 1]); zu_nxt[j + 1] = zs_unpack(zs_nxt[j + 1]); }
           __builtin_amdgcn_sched_barrier(0);
         }
         frag = p.f;
@@ -282,38 +291,41 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
   }
 }
 
-template <int NJ>
+template <int NJ, int MI = 8>
 static int pf_launch_region(const GemmArgs& a, const u32x4_t* qw_r, const uint32_t* zs_r, int NG, int cg_base, int ng_region) {
-  const int nbx = (ng_region + 4 * NJ - 1) / (4 * NJ), nby = (a.M + kPfBM - 1) / kPfBM;
-  const size_t lds = 2 * kPfBM * 256;
+  constexpr int BM = MI * 16;
+  const int nbx = (ng_region + 4 * NJ - 1) / (4 * NJ), nby = (a.M + BM - 1) / BM;
+  const size_t lds = 2 * BM * 256;
   static unsigned long long opted[2] = {0ull, 0ull};
-  if (!opt_in_dynamic_lds((const void*)gemm_repacked_pipelined_kernel<NJ>, (int)lds, opted)) return AWQ_ERR_LAUNCH;
-  hipLaunchKernelGGL(gemm_repacked_pipelined_kernel<NJ>, dim3(nbx * nby), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x, a.ldx, qw_r,
-                     zs_r, a.bias, a.y, a.M, a.K, a.N, a.g, NG, nbx, nby, cg_base, ng_region, PfMoe{nullptr, nullptr, nullptr, 0ll, 1});
+  if (!opt_in_dynamic_lds((const void*)gemm_repacked_pipelined_kernel<NJ, false, 0, MI>, (int)lds, opted)) return AWQ_ERR_LAUNCH;
+  hipLaunchKernelGGL((gemm_repacked_pipelined_kernel<NJ, false, 0, MI>), dim3(nbx * nby), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x,
+                     a.ldx, qw_r, zs_r, a.bias, a.y, a.M, a.K, a.N, a.g, NG, nbx, nby, cg_base, ng_region, PfMoe{nullptr, nullptr, nullptr, 0ll, 1});
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
 // AWQ-MoE over expert-sorted 128-row blocks: `num_blocks` row tiles x ceil(NG / 16) column tiles of 256 (the remainder tile is clamped)
-template <int EPI>
+template <int EPI, int MI>
 static int pf_launch_moe(const GemmArgs& a, const u32x4_t* qw_r, const uint32_t* zs_r, int NG, int num_blocks, const PfMoe& moe) {
   const int nbx = (NG + 15) / 16, nby = num_blocks;
-  const size_t lds = 2 * kPfBM * 256;
+  const size_t lds = 2 * MI * 16 * 256;
   static unsigned long long opted[2] = {0ull, 0ull};
-  if (!opt_in_dynamic_lds((const void*)gemm_repacked_pipelined_kernel<4, true, EPI>, (int)lds, opted)) return AWQ_ERR_LAUNCH;
-  hipLaunchKernelGGL((gemm_repacked_pipelined_kernel<4, true, EPI>), dim3(nbx * nby), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x, a.ldx,
-                     qw_r, zs_r, nullptr, a.y, num_blocks * kPfBM, a.K, a.N, a.g, NG, nbx, nby, 0, NG, moe);
+  if (!opt_in_dynamic_lds((const void*)gemm_repacked_pipelined_kernel<4, true, EPI, MI>, (int)lds, opted)) return AWQ_ERR_LAUNCH;
+  hipLaunchKernelGGL((gemm_repacked_pipelined_kernel<4, true, EPI, MI>), dim3(nbx * nby), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x,
+                     a.ldx, qw_r, zs_r, nullptr, a.y, num_blocks * MI * 16, a.K, a.N, a.g, NG, nbx, nby, 0, NG, moe);
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
 int launch_gemm_repacked_moe_tiles(const GemmArgs& a, const void* packed_experts, const int* row_map, const int* block_expert, int num_blocks,
-                                   const float* slot_scale, long long expert_stride, int x_div, bool silu_mul) {
+                                   int block_rows, const float* slot_scale, long long expert_stride, int x_div, bool silu_mul) {
   if (!pipelined_addressable(a)) return AWQ_ERR_BAD_VARIANT;
   const int NG = rp_groups(a.N);
   if (silu_mul && (NG & 1)) return AWQ_ERR_BAD_VARIANT;
   const u32x4_t* qw_r = (const u32x4_t*)packed_experts;
   const uint32_t* zs_r = (const uint32_t*)packed_experts + (size_t)NG * (a.K / 128) * 256;
   const PfMoe moe = {row_map, block_expert, slot_scale, expert_stride, x_div};
-  return silu_mul ? pf_launch_moe<1>(a, qw_r, zs_r, NG, num_blocks, moe) : pf_launch_moe<0>(a, qw_r, zs_r, NG, num_blocks, moe);
+  if (block_rows == 64) return silu_mul ? pf_launch_moe<1, 4>(a, qw_r, zs_r, NG, num_blocks, moe) : pf_launch_moe<0, 4>(a, qw_r, zs_r, NG, num_blocks, moe);
+  if (block_rows != 128) return AWQ_ERR_BAD_SHAPE;
+  return silu_mul ? pf_launch_moe<1, 8>(a, qw_r, zs_r, NG, num_blocks, moe) : pf_launch_moe<0, 8>(a, qw_r, zs_r, NG, num_blocks, moe);
 }
 
 // 32-bit offsets inside the kernel's buffer descriptors: a 128-row x tile, the scale words and one column group's strip of weights
@@ -351,6 +363,18 @@ int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed) {
   static const int env_nj2 = lab_env("AWQ_PF_NJ2", -1);      // lab knob: 0 never, 1 always
   const double cost2 = kNarrow2 * (double)((((NG + 7) / 8) * nby + 255) / 256);
   if (env_nj2 == 1 || (env_nj2 != 0 && env_split && cost2 < best - 1e-9)) return pf_launch_region<2>(a, qw_r, zs_r, NG, 0, NG);
+#ifdef AWQ_LAB
+  static const int env_mi4 = lab_env("AWQ_PF_MI4", 0);     // lab: 64-row tiles (two workgroups per CU); 1 = one launch of 256-wide tiles, 2 = with the split
+  if (env_mi4 == 1) return pf_launch_region<4, 4>(a, qw_r, zs_r, NG, 0, NG);
+  if (env_mi4 == 2) {
+    if (gA > 0) {
+      const int rc = pf_launch_region<4, 4>(a, qw_r, zs_r, NG, 0, gA);
+      if (rc) return rc;
+    }
+    if (gA < NG) return pf_launch_region<3, 4>(a, qw_r, zs_r, NG, gA, NG - gA);
+    return AWQ_OK;
+  }
+#endif
   if (gA > 0) {
     const int rc = pf_launch_region<4>(a, qw_r, zs_r, NG, 0, gA);
     if (rc) return rc;

@@ -19,6 +19,8 @@ column-interleaved tensors so SiLU·mul is the GEMV's epilogue), and a forward i
     more pairs: the pairs are sorted by expert ON THE DEVICE and cut into 16-row blocks that never straddle two experts (the
         reference's moe_align_block_size step), then two launches of `awq_aux_moe_gemv_blocks` — one expert stream per 16 rows
         instead of one per pair, same epilogues, same rounding points;
+    prefill-sized batches (more than 16 rows per expert on average): the same with 64- or 128-row blocks on the MFMA tile kernel of the
+        dense prefill path (`awq_aux_moe_gemm_blocks`);
     then one sum over each token's top_k rows.  Ids outside [0, E) (the reference marks the padded tokens of a graph batch
     with -1, layers/moe/topk.py:705-712) contribute zero.
 
@@ -67,8 +69,14 @@ class AWQMoEMethod:
     MOE_SLOT_MAX_PAIRS = 12
     MOE_GEMV_MAX_SLOTS = MOE_SLOT_MAX_PAIRS   # (name of rounds 1-2)
 
-    # average rows per expert from which the 128-row tile route (MFMA tile kernel) replaces the 16-row block route
-    TILE_ROUTE_MIN_ROWS_PER_EXPERT = 24
+    # Average rows per expert from which the MFMA tile route replaces the 16-row block route: a 16-row block streams its expert once at
+    # GEMV speed, so up to 16 rows per expert the block route costs one stream per active expert and wins or ties (Mixtral-like: 215 us
+    # against ~340; DeepSeek-V3-like: 1.7 ms either way); from 17 rows it pays a second stream while a 64-row tile does not
+    # (profiles/r03_time_moe_tile_route.txt).
+    TILE_ROUTE_MIN_ROWS_PER_EXPERT = 16
+    # Below this average load the tiles are 64 rows tall (less padding in every expert's last tile, two workgroups per CU), above it 128
+    # (Mixtral-like experts at 1024 rows each: 3662 vs 3755 us; at 512 rows a tie; DeepSeek-V3-like at 512 rows: 64-row tiles 10 % faster)
+    TILE_ROUTE_WIDE_ROWS_PER_EXPERT = 768
 
     @classmethod
     def slot_route_max_pairs(cls, num_experts: int) -> int:
@@ -150,14 +158,16 @@ class AWQMoEMethod:
         _lib.check(rc, "awq_aux_moe_gemv")
         return y
 
-    def _moe_blocks(self, x, packed, row_map, block_expert, slot_scale, pairs, x_div, K, N, silu, tiles=False):
+    def _moe_blocks(self, x, packed, row_map, block_expert, slot_scale, pairs, x_div, K, N, silu, tiles=0):
         g = self.quant_config.group_size
         # rows of padded / dropped pairs are never written by the kernel: start from zeros so the top_k sum ignores them
         y = torch.zeros((pairs, N // 2 if silu else N), dtype=torch.float16, device=x.device)
-        fn = _lib.load().awq_aux_moe_gemm_blocks if tiles else _lib.load().awq_aux_moe_gemv_blocks     # 128-row / 16-row blocks
+        # tiles = 64 / 128: rows per block on the MFMA tile kernel; 0: 16-row blocks on the GEMV
+        rows_arg = (int(tiles),) if tiles else ()
+        fn = _lib.load().awq_aux_moe_gemm_blocks if tiles else _lib.load().awq_aux_moe_gemv_blocks
         rc = fn(ctypes.c_void_p(x.data_ptr()), x.stride(0), int(x_div), ctypes.c_void_p(packed.data_ptr()),
                                                  packed.stride(0), ctypes.c_void_p(row_map.data_ptr()),
-                                                 ctypes.c_void_p(block_expert.data_ptr()), block_expert.numel(),
+                                                 ctypes.c_void_p(block_expert.data_ptr()), block_expert.numel(), *rows_arg,
                                                  ctypes.c_void_p(slot_scale.data_ptr()) if slot_scale is not None else None,
                                                  ctypes.c_void_p(y.data_ptr()), K, N, g, _lib.DTYPE_F16, 1 if silu else 0,
                                                  ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
@@ -249,11 +259,12 @@ class AWQMoEMethod:
             if act is not None:
                 y = self._moe_gemv(act, layer.w2_packed, ids, wts, pairs, 1, I, K, False, E)
         if y is None and pairs >= self.TILE_ROUTE_MIN_ROWS_PER_EXPERT * E:
-            # prefill-sized batch: 128-row blocks on the MFMA tile kernel (each active expert streamed once per 128 of its rows)
-            row_map, block_expert = self.align_blocks_device(ids, E, 128)
-            act = self._moe_blocks(x, layer.w13_packed, row_map, block_expert, None, pairs, top_k, K, 2 * I, True, tiles=True)
+            # prefill-sized batch: 64- or 128-row blocks on the MFMA tile kernel (each active expert streamed once per tile of its rows)
+            rows = 64 if pairs < self.TILE_ROUTE_WIDE_ROWS_PER_EXPERT * E else 128
+            row_map, block_expert = self.align_blocks_device(ids, E, rows)
+            act = self._moe_blocks(x, layer.w13_packed, row_map, block_expert, None, pairs, top_k, K, 2 * I, True, tiles=rows)
             if act is not None:
-                y = self._moe_blocks(act, layer.w2_packed, row_map, block_expert, wts, pairs, 1, I, K, False, tiles=True)
+                y = self._moe_blocks(act, layer.w2_packed, row_map, block_expert, wts, pairs, 1, I, K, False, tiles=rows)
         if y is None:
             row_map, block_expert = self.align_blocks_device(ids, E)
             act = self._moe_blocks(x, layer.w13_packed, row_map, block_expert, None, pairs, top_k, K, 2 * I, True)

@@ -399,7 +399,7 @@ def test_7b_dimension_layers_match_fp32_reference(B):
     assert "folded" in model.layers[0].norm_order(B) if B <= 16 else "reference" in model.layers[0].norm_order(B)
 
 
-@pytest.mark.parametrize("BS", [16, 128])
+@pytest.mark.parametrize("BS", [16, 64, 128])
 @pytest.mark.parametrize("P,E", [(1, 8), (40, 8), (600, 8), (33, 4), (5, 1), (4096, 60), (7, 1024)])
 def test_moe_align_blocks_kernel_contract(ops, P, E, BS):
     """awq_aux_moe_align_blocks_n (one-workgroup counting sort; 16-row blocks for the GEMV route, 128-row blocks for the MFMA tile route)
@@ -436,9 +436,10 @@ def test_moe_align_blocks_kernel_contract(ops, P, E, BS):
         assert got == want
 
 
-def test_moe_tile_route_matches_block_route(ops):
-    """Prefill-sized MoE batches run expert-sorted 128-row blocks on the MFMA tile kernel (awq_aux_moe_gemm_blocks:
-    gemm_repacked_pipelined_kernel<4, MOE>) instead of 16-row blocks on the GEMV (awq_aux_moe_gemv_blocks).  Same rounding points
+@pytest.mark.parametrize("wide_from", [0, 1e18], ids=["128-row tiles", "64-row tiles"])
+def test_moe_tile_route_matches_block_route(ops, wide_from):
+    """Prefill-sized MoE batches run expert-sorted 128-row (or, for thinly loaded experts, 64-row) blocks on the MFMA tile kernel
+    (awq_aux_moe_gemm_blocks: gemm_repacked_pipelined_kernel<4, MOE, EPI, MI>) instead of 16-row blocks on the GEMV (awq_aux_moe_gemv_blocks).  Same rounding points
     (fp16 gate_up -> silu * up in the epilogue -> routed weight on the fp32 sums -> one rounding); the fp32 summation order differs, so a
     rounding flips here and there: at most one fp16 ulp of an output's slots.  Padded tokens (ids -1, layers/moe/topk.py:705-712) give zero
     rows on both routes; ragged expert loads (one expert with a single row, one with none) and a width that is not a multiple of the
@@ -455,13 +456,14 @@ def test_moe_tile_route_matches_block_route(ops):
     ti[7, 1] = 4                                           # ... except by one pair
     ti[-8:] = -1                                           # padded tokens of a graph batch
     assert T * top_k >= AWQMoEMethod.TILE_ROUTE_MIN_ROWS_PER_EXPERT * E
-    y_tile = method.apply(layer, x, tw, ti)
-    saved = AWQMoEMethod.TILE_ROUTE_MIN_ROWS_PER_EXPERT
+    saved = (AWQMoEMethod.TILE_ROUTE_MIN_ROWS_PER_EXPERT, AWQMoEMethod.TILE_ROUTE_WIDE_ROWS_PER_EXPERT)
     try:
+        AWQMoEMethod.TILE_ROUTE_WIDE_ROWS_PER_EXPERT = wide_from
+        y_tile = method.apply(layer, x, tw, ti)
         AWQMoEMethod.TILE_ROUTE_MIN_ROWS_PER_EXPERT = 1e18
         y_blk = method.apply(layer, x, tw, ti)
     finally:
-        AWQMoEMethod.TILE_ROUTE_MIN_ROWS_PER_EXPERT = saved
+        AWQMoEMethod.TILE_ROUTE_MIN_ROWS_PER_EXPERT, AWQMoEMethod.TILE_ROUTE_WIDE_ROWS_PER_EXPERT = saved
     assert torch.isfinite(y_tile).all() and torch.count_nonzero(y_tile[-8:]) == 0 and torch.count_nonzero(y_blk[-8:]) == 0
     d = (y_tile.float() - y_blk.float()).abs()
     ulp = 2.0 ** (torch.floor(torch.log2(y_blk.float().abs().clamp_min(2.0 ** -14))) - 10)

@@ -17,6 +17,8 @@ if os.environ.get("MOE_SLOT_MAX_PAIRS"):            # A/B of the route threshold
     AWQMoEMethod.slot_route_max_pairs = classmethod(lambda cls, num_experts: int(os.environ["MOE_SLOT_MAX_PAIRS"]))
 if os.environ.get("MOE_TILE_MIN_ROWS"):
     AWQMoEMethod.TILE_ROUTE_MIN_ROWS_PER_EXPERT = float(os.environ["MOE_TILE_MIN_ROWS"])
+if os.environ.get("MOE_TILE_WIDE_ROWS"):
+    AWQMoEMethod.TILE_ROUTE_WIDE_ROWS_PER_EXPERT = float(os.environ["MOE_TILE_WIDE_ROWS"])
 m = AWQMoEMethod(AWQConfig(4, g, True))
 layer = torch.nn.Module()
 m.create_weights(layer, E, K, I, torch.float16)
@@ -45,7 +47,8 @@ for T in TOKENS:
     us = e0.elapsed_time(e1) * 1e3 / 50
     slots = T * top_k
     route = ("one grid row per pair" if slots <= AWQMoEMethod.slot_route_max_pairs(E) else
-             "expert-sorted 128-row tiles" if slots >= AWQMoEMethod.TILE_ROUTE_MIN_ROWS_PER_EXPERT * E else "expert-sorted 16-row blocks")
+             ("expert-sorted 64-row tiles" if slots < AWQMoEMethod.TILE_ROUTE_WIDE_ROWS_PER_EXPERT * E else "expert-sorted 128-row tiles")
+             if slots >= AWQMoEMethod.TILE_ROUTE_MIN_ROWS_PER_EXPERT * E else "expert-sorted 16-row blocks")
     active = len(set(ti.view(-1).tolist()))
     print(f"T={T:3d} pairs={slots:3d} ({route}, {active} active experts): {us:8.1f} us per MoE layer  ({active * wbytes / us / 1e3:7.1f} GB/s if every "
           f"active expert were streamed once)", flush=True)
