@@ -98,6 +98,21 @@ struct RpFuse {
                                // graph batch, layers/moe/topk.py:705-712): their output row is zero-filled, no weight is read
 };
 
+// Issue priority tied to a wave's progress (see gemv_rp2_kernel): done of total steps -> s_setprio 3 .. 0.  The waves that share a
+// SIMD then finish together instead of one trailing the others into the workgroup's reduction.  RP_DYNPRIO=0: A/B build without.
+#ifndef RP_DYNPRIO
+#define RP_DYNPRIO 1
+#endif
+__device__ __forceinline__ void prio_by_progress(int done, int total) {   // wave-uniform arguments
+#if RP_DYNPRIO
+  const int b = done * 4;
+  if (b < total) __builtin_amdgcn_s_setprio(3);
+  else if (b < 2 * total) __builtin_amdgcn_s_setprio(2);
+  else if (b < 3 * total) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 // T = k-blocks per wave when it is small enough to issue every load up front (straight-line code, exact
 // counted waits); T == 0: any count, double-buffered loop.
 template <int G, int T, int W, bool NT, int MT, int EPI = 0>
@@ -147,6 +162,7 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) buf[t].xa[d][mt] = (u32x4_t){0u, 0u, 0u, 0u};
       }
+      prio_by_progress(t, T);
       rp_compute<G, MT>(buf[t], acc);
       __builtin_amdgcn_sched_barrier(0);
       if (t == 0) RP_STAMP(2);
@@ -159,17 +175,20 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
     if (kb < kb_end) rp_load<G, NT, MT>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
     if (kb + 1 < kb_end) rp_load<G, NT, MT>(B, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 1, lane, xr);
     while (kb + 3 < kb_end) {
+      prio_by_progress(kb - kb_begin, per_wave);
       rp_compute<G, MT>(A, acc);
       rp_load<G, NT, MT>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 2, lane, xr);
       rp_compute<G, MT>(B, acc);
       rp_load<G, NT, MT>(B, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 3, lane, xr);
       kb += 2;
     }
+    prio_by_progress(kb - kb_begin, per_wave);
     if (kb < kb_end) rp_compute<G, MT>(A, acc);
     if (kb + 2 < kb_end) rp_load<G, NT, MT>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 2, lane, xr);
     if (kb + 1 < kb_end) rp_compute<G, MT>(B, acc);
     if (kb + 2 < kb_end) rp_compute<G, MT>(A, acc);
   }
+  __builtin_amdgcn_s_setprio(0);
 
   RP_STAMP(3);
   // D[m = 4q + i][n = r] per column group -> LDS, summed over the waves in fixed order
@@ -253,6 +272,9 @@ __global__ __launch_bounds__(W * 64, (W * 64) / 256) void gemv_repacked_kernel(c
 #ifndef RP2_CMAJOR
 #define RP2_CMAJOR 1          // unit i = (c = i / T, t = i % T): a wave's consecutive loads are contiguous; 0: t-major (round 2; same speed,
 #endif                        // profiles/r03_kbench_next_hint_ab.txt)
+#ifndef RP2_DYNPRIO
+#define RP2_DYNPRIO 1         // a wave's issue priority falls as it gets through its units (s_setprio 3 .. 0); 0: A/B build, the static form of
+#endif                        // round 2 (the later waves of a SIMD raised once).  profiles/r03_kbench_wave_priority_ab.txt
 #ifndef RP2_EARLY
 #define RP2_EARLY 1           // 0: A/B build, the replacement load is issued behind the unit's compute (round-2 first form)
 #endif
@@ -420,9 +442,11 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
   __builtin_amdgcn_sched_barrier(0);
 
   // VALU issue is arbitrated by priority, then age: the later waves of a SIMD (w >> 2 = 1, 2, 3) otherwise get the leftover
-  // slots and finish last; static priorities for the later half even that out (tools/gemv_lab)
+  // slots and finish last.  Round 2 raised the later half once (A/B build below); round 3 ties priority to progress (in the loop)
+#if RP2_DYNPRIO == 0
   if (wave >= 12) __builtin_amdgcn_s_setprio(2);
   else if (wave >= 8) __builtin_amdgcn_s_setprio(1);
+#endif
   uint32_t mlo = kLoNib, mhi = kHiNib, magic = kMagicF16;
   asm volatile("" : "+s"(mlo), "+s"(mhi));               // opaque: (w & m) | magic then selects v_and_or_b32 (one literal each)
   asm volatile("" : "+v"(magic));
@@ -441,6 +465,18 @@ __global__ __launch_bounds__(1024) void gemv_rp2_kernel(const uint16_t* __restri
 #pragma unroll
       for (int d = 0; d < 4; ++d) xa[d] = *(const u32x4_t*)(x_lds + t * 128 + d * 32 + q * 8);
     }
+#if RP2_DYNPRIO == 1
+    // Four waves share a SIMD's issue port, arbitrated by priority, then age.  With fixed priorities some wave of the four always runs
+    // ahead and one trails (stamps: the second-oldest wave finished its units 1.0 us after the youngest, raised one), and the trailing wave
+    // cannot fill the port alone while the workgroup's reduction waits for it.  Priority tied to progress is a feedback loop: whoever is
+    // behind outranks whoever is ahead, the four finish together.  4096 x 11008: 6.62 -> 6.32 us at one row, 8.05 -> 7.29 at eight.
+    switch (3 - (i * 4) / L) {
+      case 3: __builtin_amdgcn_s_setprio(3); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      default: __builtin_amdgcn_s_setprio(0); break;
+    }
+#endif
     const half2_t zh = as_h2(zs_lds[(c * T + t) * 16]);
     const half2_t s2 = __builtin_shufflevector(zh, zh, 0, 0);          // folded into op_sel of the packed ops
     const half2_t z1024 = __builtin_shufflevector(zh, zh, 1, 1);

@@ -146,8 +146,10 @@ __global__ __launch_bounds__(1024) void gemv_rp3_kernel(const uint16_t* __restri
   stage_store(0);
   __builtin_amdgcn_sched_barrier(0);
 
+#if !RP_DYNPRIO
   if (wave >= 12) __builtin_amdgcn_s_setprio(2);
   else if (wave >= 8) __builtin_amdgcn_s_setprio(1);
+#endif
   uint32_t mlo = kLoNib, mhi = kHiNib, magic = kMagicF16;
   asm volatile("" : "+s"(mlo), "+s"(mhi));               // opaque: (w & m) | magic then selects v_and_or_b32
   asm volatile("" : "+v"(magic));
@@ -166,6 +168,7 @@ __global__ __launch_bounds__(1024) void gemv_rp3_kernel(const uint16_t* __restri
   auto stage_body = [&](auto ph, int s) {
     constexpr int PH = decltype(ph)::value;
     const bool more = s + 1 < S;                         // uniform
+    prio_by_progress(s, S);                              // (stages done of stages: the waves of a SIMD finish together)
     if (more) stage_load(s + 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -58,17 +58,20 @@ __global__ __launch_bounds__(kRpsWaves * 64, 2) void gemv_rps_kernel(const uint1
     if (kb < kb_end) rp_load<G, true, MT>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb, lane, xr);
     if (kb + 1 < kb_end) rp_load<G, true, MT>(B, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 1, lane, xr);
     while (kb + 3 < kb_end) {
+      prio_by_progress(kb - kb_begin, per_wave);
       rp_compute<G, MT>(A, acc);
       rp_load<G, true, MT>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 2, lane, xr);
       rp_compute<G, MT>(B, acc);
       rp_load<G, true, MT>(B, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 3, lane, xr);
       kb += 2;
     }
+    prio_by_progress(kb - kb_begin, per_wave);
     if (kb < kb_end) rp_compute<G, MT>(A, acc);
     if (kb + 2 < kb_end) rp_load<G, true, MT>(A, qw_r, zs_r, x, ldx, cg0, KB, groups, g, kb + 2, lane, xr);
     if (kb + 1 < kb_end) rp_compute<G, MT>(B, acc);
     if (kb + 2 < kb_end) rp_compute<G, MT>(A, acc);
   }
+  __builtin_amdgcn_s_setprio(0);
 
   // D[m = 16 mt + 4 q + i][n = r] per column group -> LDS, summed over the waves in fixed order
 #pragma unroll

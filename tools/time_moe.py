@@ -5,6 +5,9 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from sglang_awq_amd import _lib
+if os.environ.get("AWQ_LAB_LIB"):                  # tools only: time another build of the library
+    _lib.LIB_PATH = os.path.abspath(os.environ["AWQ_LAB_LIB"])
 from sglang_awq_amd.awq import AWQConfig
 from sglang_awq_amd.moe import AWQMoEMethod, select_experts
 
