@@ -104,6 +104,21 @@ def test_aux_argument_validation_without_gpu(lib):
     assert att(splits=4, ws=vp(p), wsb=need - 1) == -5
     assert lib.awq_aux_add_rmsnorm(vp(p), None, vp(p), vp(p), 1, 100, 1e-5, None) == -2      # H % 8
     assert lib.awq_aux_silu_mul(vp(p), None, 1, 64, None) == -1
+    # AWQ-MoE block alignment and the tile route (rejections before any HIP call)
+    al = lambda **kw: lib.awq_aux_moe_align_blocks_n(kw.get("ids", vp(p)), kw.get("pairs", 100), kw.get("E", 8), kw.get("rows", 128), vp(p), vp(p),
+                                                     kw.get("B", 9), None)
+    assert al(ids=None) == -1
+    assert al(rows=32) == -2 and al(rows=0) == -2                      # block sizes: 16, 64, 128
+    assert al(B=8) == -2                                               # fewer blocks than ceil(pairs / rows) + experts
+    assert al(E=2000, B=2001) == -7                                    # more than 1024 experts: the tensor-op form (caller)
+    mg = lambda **kw: lib.awq_aux_moe_gemm_blocks(kw.get("x", vp(p)), kw.get("ldx", 4096), kw.get("x_div", 2), vp(p), kw.get("stride", 1 << 20), vp(p),
+                                                  vp(p), kw.get("B", 9), kw.get("rows", 128), None, kw.get("y", vp(p)), kw.get("K", 4096),
+                                                  kw.get("N", 4096), kw.get("g", 128), 0, kw.get("silu", 0), None)
+    assert mg(x=None) == -1 and mg(y=None) == -1
+    assert mg(rows=16) == -2 and mg(B=0) == -2 and mg(x_div=0) == -2 and mg(ldx=128) == -2
+    assert mg(stride=(1 << 20) + 4) == -6
+    assert mg(g=64) == -7                                              # no repacked form for g = 64
+    assert mg(N=4104, silu=1) == -7                                    # SiLU-mul needs whole (gate, up) pairs of 16-column groups
 
 
 def test_workspace_query(lib):
