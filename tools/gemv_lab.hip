@@ -392,6 +392,14 @@ __global__ __launch_bounds__(W * 64) void lab3_kernel(LabArgs a) {
         for (int d = 0; d < 4; ++d) xa[d] = *(const u32x4_t*)(x_lds + t * 128 + d * 32 + q * 8);
       }
     }
+    if constexpr (PRIO == 4) {          // priority falls with the wave's progress (the product form since round 3)
+      switch (3 - (i * 4) / L) {
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        default: __builtin_amdgcn_s_setprio(0); break;
+      }
+    }
     uint32_t zsv;
     if constexpr (ABL == 5 || ABL == 6) zsv = 0x64082000u + lane; else zsv = zs_lds[(c * T + t) * 16 + r];
     const u32x4_t w = wbuf[i % DD];
@@ -529,6 +537,8 @@ static const Variant kVariants4096[] = {
     V3(3, 2, 16, 2, 0, 1, 20),
     V3(3, 2, 16, 2, 0, 1, 52),
     V3(3, 2, 16, 2, 0, 1, 53),
+    V3(3, 2, 16, 2, 0, 1, 69),
+    V3(3, 2, 16, 2, 0, 1, 68),
     V3(3, 2, 16, 2, 2, 1, 52),
     V3(3, 2, 16, 2, 4, 1, 52),
     V3(3, 2, 16, 2, 5, 1, 52),
