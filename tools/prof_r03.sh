@@ -13,6 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_m1 -o m1 -- python3 $R/bench.py --steps 800 --warmup 100 --cpu-seconds 0 --sections '' > $O/prof_m1.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_sections -o sec -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --sections prefill,dequantize,op,large > $O/prof_sections.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_dec1 -o d1 -- python3 $R/bench_decode.py --batches 1 --steps 32 --cpu-seconds 0 > $O/prof_dec1.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_dec32 -o d32 -- python3 $R/bench_decode.py --batches 32 --steps 16 --cpu-seconds 0 > $O/prof_dec32.log 2>&1
 # HBM traffic of the three HBM / MFMA records: decode GEMV (M = 1), awq_dequantize, prefill (M = 2048: two launches per call)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- $R/tools/kbench rgemm 1 4096 11008 128 16 64 0 > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- $R/tools/kbench rgemm 1 4096 11008 128 16 64 0 > $O/pmc_write.log 2>&1

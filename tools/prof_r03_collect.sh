@@ -10,6 +10,7 @@ f() { find "$1" -name "$2" | head -1; }
 cp "$(f $O/prof_m1 '*kernel_stats.csv')" $P/r03_bench_m1_kernel_stats.csv
 cp "$(f $O/prof_sections '*kernel_stats.csv')" $P/r03_bench_sections_kernel_stats.csv
 cp "$(f $O/prof_dec1 '*kernel_stats.csv')" $P/r03_decode_7b_bs1_kernel_stats.csv
+d32="$(f $O/prof_dec32 '*kernel_stats.csv')"; [ -n "$d32" ] && cp "$d32" $P/r03_decode_7b_bs32_kernel_stats.csv
 # PMC passes: keep only the rows of the kernel of interest (the counter_collection csv lists every dispatch, repack included)
 keep() { head -1 "$1" > "$3"; grep "$2" "$1" >> "$3" || true; }
 keep "$(f $O/pmc_fetch '*counter_collection.csv')" gemv_rp $P/r03_pmc_fetch_size_gemv_rp2_m1.csv
