@@ -28,8 +28,9 @@ bool pow2_le32(int v) { return v >= 1 && v <= 32 && (v & (v - 1)) == 0; }
 // routes give bit-identical results).  The table of routes and the measurements behind every threshold: awq_dispatch.h.
 static int repacked_dispatch(const GemmArgs& a, const void* packed) {
   const int64_t M = a.M;
-  // <= 32 rows: the streaming GEMV.  Up to 160 rows, passes of it (32 rows each) beat the 128 x 256 MFMA tiles, which
-  // would leave most CUs idle (4096 x 11008: 13.6 us per pass vs ~62 us for one round of under-filled tiles).  Where the
+  // <= 32 rows: the streaming GEMV.  A few passes of it (32 rows each) beat the MFMA tiles while those leave most CUs idle and
+  // are bound by their K loop — how many, route::gemv_passes_max says (two on 4096 x 22016, three on 4096 x 11008, four on narrow
+  // matrices; round 2 ran passes up to 160 rows everywhere: 4096 x 22016 at 128 rows 78.6 us against 44 on tiles).  Where the
   // wide tiles are few (narrow matrices, up to 512 rows) 128 x 64 tiles with the K split inside the workgroup fill the
   // chip better (11008 x 4096 at M = 256: 142 -> 90 us); beyond that the hand-pipelined wide tiles.
   static const int env_mid = lab_env("AWQ_MID", 1);      // lab knob: 0 = never the 128 x 64 tiles
@@ -54,7 +55,9 @@ static int repacked_dispatch(const GemmArgs& a, const void* packed) {
   const bool aligned = a.ldx % 8 == 0 && (((uintptr_t)a.x) & 15) == 0;
   const int64_t wide_tiles = ((M + 127) / 128) * ((a.N + 255) / 256);
   if (env_mid != 0 && aligned && M >= route::kKsplitMinRows && wide_tiles <= route::kKsplitMaxWideTiles && repacked_fast(a.K, a.N, a.g, a.dtype)) return launch_gemm_repacked_ksplit(a, packed);
-  if (M <= route::kGemvPassesMaxRows) {
+  static const int env_passes = lab_env("AWQ_PASSES_MAX", 0);      // lab knob: rows up to which passes run (0 = the cost rule)
+  const int64_t passes_max_rows = env_passes > 0 ? env_passes : (int64_t)route::gemv_passes_max(a.K, a.N) * route::kGemvPassRows;
+  if (M <= passes_max_rows) {
     const size_t eb2 = 2;
     for (int64_t m0 = 0; m0 < M; m0 += route::kGemvPassRows) {
       GemmArgs c = a;

@@ -16,7 +16,9 @@
 //  2..32 (rest)  anything else, N <= 32768                 gemv_repacked_kernel (round 1: 8 / 16 waves,    17..32 rows: two row tiles per fragment, 8 waves
 //                                                          straight-line or double-buffered loop)
 //  1..32         N > 32768                                 gemv_repacked_kernel, rounds of 3-group strips  8192 x 57344: 145 -> 51 (G = 3; 53 / 54.5 / 60 at G = 2 / 4 / 1)
-//  33..160       any                                       passes of <= 32 rows of the GEMV                4096 x 11008: 13.6 per pass vs ~62 for one round of wide tiles
+//  33..160       while passes cost less than the tiles     passes of <= 32 rows of the GEMV                a pass 10.3 / 13.2 / 19.7 / 22.8 us on 4096 x 4096 / x 11008 / x 22016 /
+//                (gemv_passes_max: 2..4 passes)                                                           11008 x 4096; under-filled tiles ~1.12 us per k-block: 37-44 / 91 us
+//                                                                                                         (r03_kbench_middle_rows_ab.txt: 4096 x 22016 at 128 rows 78.6 -> 44)
 //  97..          <= 64 wide tiles (narrow matrices)        gemm_repacked_ksplit_kernel (128 x 64 tiles)    11008 x 4096 at 256 / 512 rows 142 -> 90 / 97
 //  161..         any                                       gemm_repacked_pipelined_kernel: 128 x 256 tiles 2048 x 4096 x 11008: 206.6 -> 200.3 with the wide + narrow
 //                                                          for whole rounds + 128 x 192 for the rest,      split; 192 / 256 rows 51.5 -> 43 with 128 x 128 tiles
@@ -35,7 +37,18 @@ namespace route {
 // ---- rows -> route (awq_capi.hip: repacked_dispatch)
 constexpr int kGemvMaxRows = 32;              // one launch of the streaming GEMV
 constexpr int kGemvPassRows = 32;             // rows per pass when a batch runs as passes of the GEMV
-constexpr int kGemvPassesMaxRows = 160;       // up to here passes beat under-filled 128 x 256 tiles
+constexpr int kGemvPassesMaxRows = 160;       // never more passes than this many rows' worth; fewer where the tiles are cheaper (gemv_passes_max)
+// Passes of the 32-row GEMV against one launch of under-filled MFMA tiles (33 .. 160 rows).  Measured: a pass costs about
+// 8 us + 0.26 us per MB of packed weight (2.5 x the per-MB term on deep matrices, K > 8192, where the 32-row kernel has no split-K form
+// without a workspace); the tile kernel with at most one tile per CU is bound by its K loop, about 1.12 us per k-block + 2 us.
+// Returns how many passes may run before the tiles win.
+inline int gemv_passes_max(int64_t K, int64_t N) {
+  const double mb = (double)K * (double)N / 2.0 / 1.0e6;
+  const double t_pass = 8.0 + 0.26 * mb * (K > 8192 ? 2.5 : 1.0);
+  const double t_tiles = 1.12 * (double)(K / 128) + 2.0;
+  int p = (int)(t_tiles / t_pass + 0.35);
+  return p < 1 ? 1 : (p > kGemvPassesMaxRows / kGemvPassRows ? kGemvPassesMaxRows / kGemvPassRows : p);
+}
 constexpr int kKsplitMinRows = 97;            // 128 x 64 K-split tiles from here ...
 constexpr int kKsplitMaxWideTiles = 64;       // ... while the 128 x 256 tiling would give at most this many tiles
 constexpr int kSplitKMinRows = 9;             // split-K GEMV (needs a workspace) from here
