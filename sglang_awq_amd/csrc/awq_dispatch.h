@@ -40,7 +40,7 @@ constexpr int kGemvPassRows = 32;             // rows per pass when a batch runs
 constexpr int kGemvPassesMaxRows = 160;       // never more passes than this many rows' worth; fewer where the tiles are cheaper (gemv_passes_max)
 // Passes of the 32-row GEMV against one launch of under-filled MFMA tiles (33 .. 160 rows).  Measured: a pass costs about
 // 8 us + 0.26 us per MB of packed weight (2.5 x the per-MB term on deep matrices, K > 8192, where the 32-row kernel has no split-K form
-// without a workspace); the tile kernel with at most one tile per CU is bound by its K loop, about 1.12 us per k-block + 2 us.
+// without a workspace); the tile kernel with at most one tile per CU takes about 1.12 us per k-block + 2 us (64 MFMAs per wave and block).
 // Returns how many passes may run before the tiles win.
 inline int gemv_passes_max(int64_t K, int64_t N) {
   const double mb = (double)K * (double)N / 2.0 / 1.0e6;
