@@ -132,13 +132,16 @@ int awq_gemm_repacked(const void* x, int64_t ldx, const void* packed, const void
                       int64_t K, int64_t N, int64_t group_size, int dtype, void* stream);
 
 /*
- * awq_gemm_repacked with an optional scratch buffer.  With 9 .. 32 rows on a narrow matrix (N <= 8192) the one-strip-per-workgroup
- * GEMV re-reads all of x in every workgroup; given `workspace` (>= awq_gemm_repacked_workspace_bytes(), 16-byte aligned, its first
- * 4096 bytes zero-filled ONCE when allocated — arrival counters, left at zero by every call — one buffer per stream of execution,
- * the same rules as awq_gemm's) that case runs wide strips with K split across workgroups instead (fp32 partials summed in fixed
- * order by the last workgroup to arrive: deterministic; sums agree with the no-workspace route to fp32 rounding, not bit for
- * bit).  workspace == NULL or too small: exactly awq_gemm_repacked.  awq_gemm_repacked_workspace_bytes returns 0 where the
- * scratch would not be used.
+ * awq_gemm_repacked with an optional scratch buffer (>= awq_gemm_repacked_workspace_bytes(), 16-byte aligned, its first 4096 bytes
+ * zero-filled ONCE when allocated — arrival counters, left at zero by every call — one buffer per stream of execution, the same rules
+ * as awq_gemm's).  Two routes use it:
+ *   9 .. 32 rows on a narrow matrix (N <= 8192): the one-strip-per-workgroup GEMV re-reads all of x in every workgroup; with the scratch
+ *     that case runs wide strips with K split across workgroups (fp32 partials summed in fixed order by the last workgroup to arrive);
+ *   33 rows and up where the MFMA tiling leaves most CUs without a tile (narrow or deep matrices, up to a few hundred rows): the tile
+ *     kernel runs with K split over workgroups, fp32 partial tiles go to the scratch and a second small launch adds them in slice order,
+ *     adds the bias and rounds once (11008 x 4096 at 128 rows: 89 -> 29 us).
+ * Both are deterministic; sums agree with the no-workspace routes to fp32 rounding, not bit for bit.  workspace == NULL or too small:
+ * exactly awq_gemm_repacked.  awq_gemm_repacked_workspace_bytes returns 0 where the scratch would not be used (at most 4096 + 32 MiB).
  */
 size_t awq_gemm_repacked_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t group_size, int dtype);
 

@@ -54,6 +54,11 @@ static int repacked_dispatch(const GemmArgs& a, const void* packed) {
   if (!repacked_fast(a.K, a.N, a.g, a.dtype)) return launch_gemm_repacked_tiled(a, packed);   // bf16 / g in {32, 64}: the generic tiles from 33 rows on
   const bool aligned = a.ldx % 8 == 0 && (((uintptr_t)a.x) & 15) == 0;
   const int64_t wide_tiles = ((M + 127) / 128) * ((a.N + 255) / 256);
+  static const int env_sk = lab_env("AWQ_PF_SK", 1);     // lab knob: 0 = never the split-K tile route
+  if (env_sk != 0 && aligned && wide_tiles <= route::kPfSplitMaxWideTiles && M >= route::kPfSplitMinRows) {
+    const int rs = launch_gemm_repacked_split_tiles(a, packed);      // under-filled tiles + workspace: K split over workgroups
+    if (rs != AWQ_ERR_BAD_VARIANT) return rs;
+  }
   if (env_mid != 0 && aligned && M >= route::kKsplitMinRows && wide_tiles <= route::kKsplitMaxWideTiles && repacked_fast(a.K, a.N, a.g, a.dtype)) return launch_gemm_repacked_ksplit(a, packed);
   static const int env_passes = lab_env("AWQ_PASSES_MAX", 0);      // lab knob: rows up to which passes run (0 = the cost rule)
   const int64_t passes_max_rows = env_passes > 0 ? env_passes : (int64_t)route::gemv_passes_max(a.K, a.N) * route::kGemvPassRows;
@@ -197,7 +202,8 @@ int awq_repack(const int32_t* qweight, const void* scales, const int32_t* qzeros
 
 size_t awq_gemm_repacked_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t group_size, int dtype) {
   if (!repacked_fast(K, N, group_size, dtype)) return 0;
-  return rps_workspace_bytes(M, K, N);
+  const size_t a = rps_workspace_bytes(M, K, N), b = pf_split_workspace_bytes(M, K, N);      // split-K GEMV (9 .. 32 rows) / split-K tiles (33 rows up)
+  return a > b ? a : b;
 }
 
 int awq_gemm_repacked(const void* x, int64_t ldx, const void* packed, const void* bias, void* y, int64_t M, int64_t K,

@@ -19,7 +19,10 @@
 //  33..160       while passes cost less than the tiles     passes of <= 32 rows of the GEMV                a pass 10.3 / 13.2 / 19.7 / 22.8 us on 4096 x 4096 / x 11008 / x 22016 /
 //                (gemv_passes_max: 2..4 passes)                                                           11008 x 4096; under-filled tiles ~1.12 us per k-block: 37-44 / 91 us
 //                                                                                                         (r03_kbench_middle_rows_ab.txt: 4096 x 22016 at 128 rows 78.6 -> 44)
-//  97..          <= 64 wide tiles (narrow matrices)        gemm_repacked_ksplit_kernel (128 x 64 tiles)    11008 x 4096 at 256 / 512 rows 142 -> 90 / 97
+//  33..          few wide tiles, workspace given           gemm_repacked_pipelined_kernel with K split     11008 x 4096 at 128 / 256 rows 88.8 -> 28.6 / 88.9 -> 41.9; 8192 x 8192 at 128
+//                (pf_split_plan)                           over workgroups + pf_splitk_reduce_kernel       rows 76.2 -> 38.7; 4096 x 11008 at 96 / 128 rows 39.5 -> 30.0 / 38.6 -> 32.9
+//                                                                                                         (r03_kbench_split_tiles_ab.txt)
+//  97..          <= 64 wide tiles, no workspace            gemm_repacked_ksplit_kernel (128 x 64 tiles)    11008 x 4096 at 256 / 512 rows 142 -> 90 / 97
 //  161..         any                                       gemm_repacked_pipelined_kernel: 128 x 256 tiles 2048 x 4096 x 11008: 206.6 -> 200.3 with the wide + narrow
 //                                                          for whole rounds + 128 x 192 for the rest,      split; 192 / 256 rows 51.5 -> 43 with 128 x 128 tiles
 //                                                          or 128 x 128 when few row tiles                 (r02_kbench_prefill_split_ab.txt, …_nj2_ab.txt)
@@ -52,6 +55,14 @@ inline int gemv_passes_max(int64_t K, int64_t N) {
 constexpr int kKsplitMinRows = 97;            // 128 x 64 K-split tiles from here ...
 constexpr int kKsplitMaxWideTiles = 64;       // ... while the 128 x 256 tiling would give at most this many tiles
 constexpr int kSplitKMinRows = 9;             // split-K GEMV (needs a workspace) from here
+constexpr int kPfSplitMaxSlices = 8;          // split-K MFMA tiles (under-filled launches, workspace given): at most this many slices ...
+constexpr int kPfSplitMinBlocks = 4;          // ... of at least this many k-blocks each
+constexpr int kPfSplitMinRows = 33;           // ... from this many rows
+constexpr int kPfSplitFewWideTiles = 48;      // ... when the 128 x 256 tiling gives at most this many tiles,
+constexpr int kPfSplitDeepBlocks = 64;        // ... or, on matrices at least this many k-blocks deep,
+constexpr int kPfSplitMaxWideTiles = 128;     // ... at most this many;
+constexpr int kPfSplitNarrowWideTiles = 32;   // ... up to 64 rows only where even fewer (the GEMV passes win on wider matrices there)
+constexpr int kPfSplitNarrowTilesMax = 64;    // 128 x 128 tiles while there are at most this many of them, 128 x 256 beyond
 constexpr int64_t kRepackOnTheFlyMinM = 33;   // the op re-lays the weight out per call from here (no cached copy)
 
 // ---- the GEMV family (awq_repacked.hip: launch_gemv_repacked)

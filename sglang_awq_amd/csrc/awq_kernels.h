@@ -87,6 +87,10 @@ int launch_gemv_repacked_moe(const GemmArgs& a, const void* packed);     // expe
 int launch_gemm_repacked_tiled(const GemmArgs& a, const void* packed);   // any M, MFMA-bound prefill shapes
 int launch_gemm_repacked_ksplit(const GemmArgs& a, const void* packed);      // 128 x 64 tiles, K split inside the workgroup (middle M)
 int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed);   // its hand-pipelined 128 x 256 form (awq_repacked_prefill.hip)
+// under-filled launches with a workspace: the same tiles with K split over workgroups + a reduce launch; BAD_VARIANT where it does not apply
+int launch_gemm_repacked_split_tiles(const GemmArgs& a, const void* packed);
+bool pf_split_plan(const GemmArgs& a, int* NJ_out, int* S_out, int* kb_per_out);
+size_t pf_split_workspace_bytes(int64_t M, int64_t K, int64_t N);
 // the same kernel over expert-sorted 128-row blocks of (token, expert) pairs (AWQ-MoE prefill; awq_aux_moe_gemm_blocks)
 int launch_gemm_repacked_moe_tiles(const GemmArgs& a, const void* packed_experts, const int* row_map, const int* block_expert, int num_blocks,
                                    int block_rows, const float* slot_scale, long long expert_stride, int x_div, bool silu_mul);

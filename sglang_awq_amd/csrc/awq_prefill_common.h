@@ -26,6 +26,7 @@ __device__ __forceinline__ ZsU zs_unpack(uint32_t zs) {
 }
 
 constexpr int kPfBM = 128;                        // rows per workgroup tile
+constexpr size_t kPfSplitHead = 4096;             // the workspace's counter head (zero between calls: other routes' tickets) is left alone
 constexpr int kPfRsrcFlags = 0x00020000;          // raw buffer descriptor, 32-bit data format (gfx9 family)
 
 }  // namespace awq

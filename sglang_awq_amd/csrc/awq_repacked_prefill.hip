@@ -59,6 +59,15 @@ struct PfMoe {
   int x_div;
 };
 
+// Split-K over workgroups for under-filled launches (few tiles, 33 .. ~512 rows): S slices of kb_per k-blocks each; a workgroup writes its
+// fp32 partial tile to part[slice][M][N] with plain stores and pf_splitk_reduce_kernel (a second launch: the kernel boundary orders them,
+// fixed slice order, deterministic) adds the slices, the bias, and rounds once.  part == nullptr: one slice, the epilogue rounds and stores.
+struct PfSplit {
+  float* part;
+  int S;
+  int kb_per;
+};
+
 // NJ = column groups (16 columns) per wave: 4 -> 128 x 256 tiles, 3 -> 128 x 192 tiles, 2 -> 128 x 128 tiles.
 // A launch covers the column groups [cg_base, cg_base + ng_region) of the matrix; the host cuts N into a region of 256-wide
 // tiles that fills whole rounds of the 256 CUs and a remainder of 192-wide tiles, so that 2048 x 11008 costs 2 + 0.75 rounds
@@ -69,7 +78,7 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
                                                                                 const uint32_t* __restrict__ zs_r,
                                                                                 const void* __restrict__ bias, void* __restrict__ y, int M,
                                                                                 int K, int N, int g, int NG, int nbx, int nby, int cg_base,
-                                                                                int ng_region, PfMoe moe) {
+                                                                                int ng_region, PfMoe moe, PfSplit split) {
   static_assert(!EPI || (MOE && NJ % 2 == 0), "SiLU-mul epilogue: whole (gate, up) pairs per wave");
   static_assert(MI == 8 || MI == 4, "128- or 64-row tiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char As[];      // 2 x 32 KiB
@@ -79,11 +88,14 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform on purpose: every weight / scale address below is
   const int q = lane >> 4, r = lane & 15;                          // an SGPR base + a 32-bit lane offset (no 64-bit VALU address math
-  const int KB = K / 128, groups = K / g, kpg = g / 128;           // in the loop: it is not hidden behind the MFMAs)
+  const int KBT = K / 128, groups = K / g, kpg = g / 128;          // in the loop: it is not hidden behind the MFMAs)
 
-  const int nwg = nbx * nby, bid = blockIdx.x;
+  const int ntile = nbx * nby, nwg = ntile * split.S, bid = blockIdx.x;
   const int xcd = bid & 7, qd = nwg >> 3, rem = nwg & 7;
-  const int logical = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (bid >> 3);
+  const int logical_all = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (bid >> 3);
+  const int slice = logical_all / ntile, logical = logical_all - slice * ntile;
+  const int k0 = slice * split.kb_per;                              // this workgroup's k-blocks: [k0, k0 + KB)
+  const int KB = split.S > 1 ? (KBT - k0 < split.kb_per ? KBT - k0 : split.kb_per) : KBT;
   const int bm = (logical / nbx) * BM;
   const int cg_tile = cg_base + (logical % nbx) * (4 * NJ) + wn * NJ;       // this wave's first column group
   const int cg_end = cg_base + ng_region < NG ? cg_base + ng_region : NG;
@@ -103,11 +115,11 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
   for (int j = 0; j < NJ; ++j) {
     const int c = cg_tile + j;
     const int cgj = c < cg_end ? c : cg_end - 1;       // clamped: groups outside the region are never stored
-    rw[j] = __builtin_amdgcn_make_buffer_rsrc((void*)(qw_r + (size_t)cgj * KB * 64), 0, KB * 1024, kRsrcFlags);
+    rw[j] = __builtin_amdgcn_make_buffer_rsrc((void*)(qw_r + ((size_t)cgj * KBT + k0) * 64), 0, KB * 1024, kRsrcFlags);
     zoff_s[j] = (uint32_t)cgj * (uint32_t)groups * 64u;
   }
   const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)zs_r, 0, 0x7fffffff, kRsrcFlags);
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (MOE ? (size_t)0 : (size_t)bm * ldx)), 0, 0x7fffffff, kRsrcFlags);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (MOE ? (size_t)0 : (size_t)bm * ldx) + (size_t)k0 * 128), 0, 0x7fffffff, kRsrcFlags);
   const int lane16 = lane * 16, r4 = r * 4;
 
   u32x4_t a_st[AL];
@@ -152,8 +164,8 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
 
   // prologue: x tile 0 into LDS, k-block 0's weights / scales in registers, its first fragment dequantised
   load_a(0);
-  load_b(w_cur, zs_nxt, 0, 0);
-  int grp_n = 0, cnt_n = 0;                            // quantisation group of the next k-block, counted up (no division in the loop)
+  int grp_n = k0 / kpg, cnt_n = k0 - grp_n * kpg;      // quantisation group of the next k-block, counted up (no division in the loop)
+  load_b(w_cur, zs_nxt, 0, grp_n);
 #pragma unroll
   for (int i = 0; i < AL; ++i) store_a1(0, i);
 #pragma unroll
@@ -284,10 +296,25 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
             const int n = (cg_tile + j) * 16 + r;
-            if (cg_tile + j < cg_end && n < N) store_output<AWQ_DTYPE_F16>(y, (size_t)m * N + n, acc[mi][j][i], bias, n);
+            if (cg_tile + j < cg_end && n < N) {
+              if (split.part != nullptr) split.part[((size_t)slice * M + m) * N + n] = acc[mi][j][i];       // (uniform)
+              else store_output<AWQ_DTYPE_F16>(y, (size_t)m * N + n, acc[mi][j][i], bias, n);
+            }
           }
         }
       }
+  }
+}
+
+// y[m][n] = fp16(sum over slices of part[s][m][n]) (+ bias): slice order, one rounding — the second launch of the split-K tile route
+__global__ __launch_bounds__(256) void pf_splitk_reduce_kernel(const float* __restrict__ part, const void* __restrict__ bias, void* __restrict__ y,
+                                                               int S, size_t MN, int N) {
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < MN; i += (size_t)gridDim.x * 1024) {
+    float4_t v = *(const float4_t*)(part + i);
+    for (int s2 = 1; s2 < S; ++s2) v += *(const float4_t*)(part + (size_t)s2 * MN + i);
+    const int n = (int)(i % (size_t)N);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) store_output<AWQ_DTYPE_F16>(y, i + j, v[j], bias, n + j);
   }
 }
 
@@ -299,7 +326,8 @@ static int pf_launch_region(const GemmArgs& a, const u32x4_t* qw_r, const uint32
   static unsigned long long opted[2] = {0ull, 0ull};
   if (!opt_in_dynamic_lds((const void*)gemm_repacked_pipelined_kernel<NJ, false, 0, MI>, (int)lds, opted)) return AWQ_ERR_LAUNCH;
   hipLaunchKernelGGL((gemm_repacked_pipelined_kernel<NJ, false, 0, MI>), dim3(nbx * nby), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x,
-                     a.ldx, qw_r, zs_r, a.bias, a.y, a.M, a.K, a.N, a.g, NG, nbx, nby, cg_base, ng_region, PfMoe{nullptr, nullptr, nullptr, 0ll, 1});
+                     a.ldx, qw_r, zs_r, a.bias, a.y, a.M, a.K, a.N, a.g, NG, nbx, nby, cg_base, ng_region, PfMoe{nullptr, nullptr, nullptr, 0ll, 1},
+                     PfSplit{nullptr, 1, 0});
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
@@ -311,7 +339,7 @@ static int pf_launch_moe(const GemmArgs& a, const u32x4_t* qw_r, const uint32_t*
   static unsigned long long opted[2] = {0ull, 0ull};
   if (!opt_in_dynamic_lds((const void*)gemm_repacked_pipelined_kernel<4, true, EPI, MI>, (int)lds, opted)) return AWQ_ERR_LAUNCH;
   hipLaunchKernelGGL((gemm_repacked_pipelined_kernel<4, true, EPI, MI>), dim3(nbx * nby), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x,
-                     a.ldx, qw_r, zs_r, nullptr, a.y, num_blocks * MI * 16, a.K, a.N, a.g, NG, nbx, nby, 0, NG, moe);
+                     a.ldx, qw_r, zs_r, nullptr, a.y, num_blocks * MI * 16, a.K, a.N, a.g, NG, nbx, nby, 0, NG, moe, PfSplit{nullptr, 1, 0});
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
@@ -333,6 +361,81 @@ int launch_gemm_repacked_moe_tiles(const GemmArgs& a, const void* packed_experts
 bool pipelined_addressable(const GemmArgs& a) {
   const int64_t NG = rp_groups(a.N);
   return a.ldx < (int64_t(1) << 22) && NG * (a.K / a.g) * 64 < (int64_t(1) << 31) && (int64_t)(a.K / 128) * 1024 < (int64_t(1) << 31);
+}
+
+// Split-K tile route: S slices x tiles workgroups write fp32 partials into the workspace (behind its 4096-byte counter head), a second
+// launch adds them.  NJ = 2 (128 x 128) or 4 (128 x 256) tiles.
+template <int NJ>
+static int pf_launch_split(const GemmArgs& a, const u32x4_t* qw_r, const uint32_t* zs_r, int NG, int S, int kb_per) {
+  const int nbx = (NG + 4 * NJ - 1) / (4 * NJ), nby = (a.M + kPfBM - 1) / kPfBM;
+  const size_t lds = 2 * kPfBM * 256;
+  static unsigned long long opted[2] = {0ull, 0ull};
+  if (!opt_in_dynamic_lds((const void*)gemm_repacked_pipelined_kernel<NJ, false, 0, 8>, (int)lds, opted)) return AWQ_ERR_LAUNCH;
+  float* part = (float*)((char*)a.workspace + kPfSplitHead);
+  hipLaunchKernelGGL((gemm_repacked_pipelined_kernel<NJ, false, 0, 8>), dim3(nbx * nby * S), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x,
+                     a.ldx, qw_r, zs_r, nullptr, a.y, a.M, a.K, a.N, a.g, NG, nbx, nby, 0, NG, PfMoe{nullptr, nullptr, nullptr, 0ll, 1},
+                     PfSplit{part, S, kb_per});
+  const size_t MN = (size_t)a.M * a.N;
+  const unsigned blocks = (unsigned)((MN / 4 + 255) / 256 < 2048 ? (MN / 4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(pf_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, a.stream, (const float*)part, a.bias, a.y, S, MN, a.N);
+  return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
+
+// Plan of the split-K tile route: false = not applicable (no workspace, too many tiles, too few k-blocks, N % 4)
+bool pf_split_plan(const GemmArgs& a, int* NJ_out, int* S_out, int* kb_per_out) {
+  if (!a.workspace || (((uintptr_t)a.workspace) & 15) || a.workspace_bytes <= kPfSplitHead || a.N % 4 || !pipelined_addressable(a)) return false;
+  static const int env_s = lab_env("AWQ_PF_SK_S", 0), env_nj = lab_env("AWQ_PF_SK_NJ", 0);       // lab knobs: force slices / tile width (S = 1: off)
+  if (env_s == 1) return false;
+  const int NG = rp_groups(a.N), KBT = a.K / 128, nby = (a.M + kPfBM - 1) / kPfBM;
+  const size_t slice_bytes = (size_t)a.M * a.N * sizeof(float);
+  const int s_ws = (int)((a.workspace_bytes - kPfSplitHead) / slice_bytes);
+  // Where it pays (profiles/r03_kbench_split_tiles_ab.txt): few wide tiles (<= 48, or <= 128 on deep matrices with >= 64 k-blocks), and from 65
+  // rows unless the matrix is narrow (<= 32 wide tiles) — below that the GEMV passes win on wide matrices.  128 x 128 tiles while there are at
+  // most 64 of them (fewer slices for the same number of workgroups: less partial traffic), 128 x 256 beyond.
+  const int wide_tiles = ((NG + 15) / 16) * nby;
+  if (!env_s && !env_nj) {
+    const bool few = wide_tiles <= route::kPfSplitFewWideTiles || (KBT >= route::kPfSplitDeepBlocks && wide_tiles <= route::kPfSplitMaxWideTiles);
+    if (!few || (a.M <= 64 && wide_tiles > route::kPfSplitNarrowWideTiles)) return false;
+  }
+  int best_nj = 0, best_s = 0;
+  const int tiles2 = ((NG + 7) / 8) * nby;
+  for (int pass = 0; pass < 2 && !best_nj; ++pass) {
+    const int nj = env_nj ? env_nj : ((tiles2 <= route::kPfSplitNarrowTilesMax) == (pass == 0) ? 2 : 4);
+    const int tiles = ((NG + 4 * nj - 1) / (4 * nj)) * nby;
+    int S = env_s ? env_s : 256 / tiles;                  // fill the chip once
+    if (S > route::kPfSplitMaxSlices) S = route::kPfSplitMaxSlices;
+    if (S > s_ws) S = s_ws;
+    if (S > KBT / route::kPfSplitMinBlocks) S = KBT / route::kPfSplitMinBlocks;
+    if (S >= 2) { best_nj = nj; best_s = S; }
+    if (env_nj) break;
+  }
+  if (!best_nj) return false;
+  const int kb_per = (KBT + best_s - 1) / best_s;
+  *NJ_out = best_nj; *S_out = (KBT + kb_per - 1) / kb_per; *kb_per_out = kb_per;
+  return *S_out >= 2;
+}
+
+// Scratch the split-K tile route would use for this shape (0: not applicable), at most kPfSplitHead + 32 MiB (the budget of the Python
+// shim's per-stream buffer): the plan with as many slices as fit.
+size_t pf_split_workspace_bytes(int64_t M, int64_t K, int64_t N) {
+  if (M < route::kPfSplitMinRows || N % 4 || K % 128) return 0;
+  const int64_t wide_tiles = ((M + 127) / 128) * ((N + 255) / 256);
+  if (wide_tiles > route::kPfSplitMaxWideTiles) return 0;
+  const size_t slice_bytes = (size_t)M * N * sizeof(float), budget = (size_t)32 << 20;
+  int S = (int)(256 / wide_tiles) * 2;                      // (the narrow tiling may take twice the slices of the wide one; the plan decides)
+  if (S > route::kPfSplitMaxSlices) S = route::kPfSplitMaxSlices;
+  if (S > (int)(K / 128) / route::kPfSplitMinBlocks) S = (int)(K / 128) / route::kPfSplitMinBlocks;
+  if ((size_t)S * slice_bytes > budget) S = (int)(budget / slice_bytes);
+  return S >= 2 ? kPfSplitHead + (size_t)S * slice_bytes : 0;
+}
+
+int launch_gemm_repacked_split_tiles(const GemmArgs& a, const void* packed) {
+  int NJ = 0, S = 0, kb_per = 0;
+  if (!pf_split_plan(a, &NJ, &S, &kb_per)) return AWQ_ERR_BAD_VARIANT;
+  const int NG = rp_groups(a.N);
+  const u32x4_t* qw_r = (const u32x4_t*)packed;
+  const uint32_t* zs_r = (const uint32_t*)packed + (size_t)NG * (a.K / 128) * 256;
+  return NJ == 4 ? pf_launch_split<4>(a, qw_r, zs_r, NG, S, kb_per) : pf_launch_split<2>(a, qw_r, zs_r, NG, S, kb_per);
 }
 
 int launch_gemm_repacked_pipelined(const GemmArgs& a, const void* packed) {

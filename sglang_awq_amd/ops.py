@@ -386,8 +386,9 @@ def awq_gemm_repacked(input: torch.Tensor, packed: torch.Tensor, K: int, N: int,
     with _on_device(dev):
         y = torch.empty((M, N), dtype=dt, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        if 8 < M <= 32 and lib.awq_gemm_repacked_workspace_bytes(M, K, N, group_size, _DTYPE_CODE[dt]):
-            # narrow matrix, many rows: the split-K route wants the per-(device, stream) scratch (counters + fp32 partials)
+        if M > 8 and lib.awq_gemm_repacked_workspace_bytes(M, K, N, group_size, _DTYPE_CODE[dt]):
+            # 9 .. 32 rows on a narrow matrix (split-K GEMV) or 33 rows up with few MFMA tiles (split-K tiles): both want the
+            # per-(device, stream) scratch (counters + fp32 partials)
             ws = _workspace(dev, stream)
             rc = lib.awq_gemm_repacked_ws(_vp(input), ldx, _vp(packed), _vp(bias), _vp(y), _vp(ws), ws.numel(), M, K, N, group_size,
                                           _DTYPE_CODE[dt], ctypes.c_void_p(stream))

@@ -541,3 +541,55 @@ def test_tiny_llama_long_context_every_batch_regime():
                 tokens = want.argmax(-1)
                 pos = pos + 1
     assert len(seen_splits) >= 3, seen_splits
+
+
+@pytest.mark.parametrize("M,K,N,g,bias", [(128, 11008, 4096, 128, False), (100, 4096, 4096, 128, True), (65, 8192, 8192, 128, False),
+                                            (96, 4096, 11008, 128, False), (33, 2048, 1032, 128, True), (384, 4096, 4096, 4096, False)])
+def test_split_k_tiles_vs_oracle(ops, M, K, N, g, bias):
+    """33 rows and up with few MFMA tiles (narrow or deep matrices): `awq_gemm_repacked_ws` splits K over workgroups on the tile kernel
+    (gemm_repacked_pipelined_kernel with PfSplit: fp32 partials in the workspace, pf_splitk_reduce_kernel adds them in slice order, adds the
+    bias and rounds once).  Against the oracle; run-to-run bit-identical (fixed order, no atomics); the no-workspace entry point (tiles /
+    passes without the split) gives the same values up to the order of the fp32 sums; ragged M and N, the bias epilogue and a single
+    quantisation group are covered; the route survives graph capture."""
+    lib = _lib.load()
+    need = lib.awq_gemm_repacked_workspace_bytes(M, K, N, g, 0)
+    assert need > 4096, "the shape was meant to take the split-K tile route"
+    qw, s, qz = synth.make_awq_weights(K, N, g, "f16", "A", seed=M + K + N)
+    x = synth.make_activations(M, K, "f16", "A", seed=M + 11)
+    b = synth.make_bias(N, "f16", 5) if bias else None
+    packed = ops.awq_repack(*[to_torch(t, DEV) for t in (qw, s, qz)])
+    xt = to_torch(x, DEV)
+    bt = to_torch(b, DEV) if bias else None
+    y1 = ops.awq_gemm_repacked(xt, packed, K, N, g, bias=bt)
+    y2 = ops.awq_gemm_repacked(xt, packed, K, N, g, bias=bt)
+    assert torch.equal(y1, y2), "split-K tiles: not run-to-run identical"
+    _, exact = c_oracle.gemm(x, qw, s, qz, want_exact=True)
+    if bias:
+        from tests.util import ulp
+        pre = exact.astype(np.float16).astype(np.float64)                     # the reference rounds the product ...
+        want = (pre + b.astype(np.float64)).astype(np.float16).astype(np.float64)        # ... adds the bias and rounds again (awq.py:447-449)
+        got = to_np(y1).astype(np.float64)
+        # one ulp of the PRE-bias sum (a rounding-boundary flip of the fp32 sum against the exact one; several ulps of a smaller post-bias
+        # result where the bias cancels) and one of the result (tests/test_gpu_parity.py: bias epilogue)
+        assert np.all(np.abs(got - want) <= 1.01 * (ulp(want, "f16") + ulp(pre, "f16"))), f"bias epilogue M={M} K={K} N={N}"
+    else:
+        assert_gemm_close(to_np(y1), exact, "f16", what=f"split-K tiles M={M} K={K} N={N} g={g}")
+    y0 = torch.empty_like(y1)
+    rc = lib.awq_gemm_repacked(ctypes.c_void_p(xt.data_ptr()), K, ctypes.c_void_p(packed.data_ptr()), ctypes.c_void_p(bt.data_ptr()) if bias else None,
+                               ctypes.c_void_p(y0.data_ptr()), M, K, N, g, 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert (y0 != y1).float().mean().item() < 0.05          # different summation order: a rounding flips here and there at most
+    assert (y0.float() - y1.float()).abs().max().item() <= 2.0 ** (np.floor(np.log2(max(1e-3, float(y1.float().abs().max())))) - 9)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.prepare_stream_workspaces(side, torch.device(DEV))
+        warm = ops.awq_gemm_repacked(xt, packed, K, N, g, bias=bt)
+    torch.cuda.current_stream().wait_stream(side)
+    gph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gph, stream=side):
+        cap = ops.awq_gemm_repacked(xt, packed, K, N, g, bias=bt)
+    gph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(cap, y1) and torch.equal(warm, y1)

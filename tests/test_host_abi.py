@@ -214,9 +214,13 @@ def test_repacked_entry_points_refuse_shapes_without_a_layout(lib):
     # the workspace variant validates the same way (nothing is launched: every call fails before the dispatch)
     assert lib.awq_gemm_repacked_ws(vp(p), 4096, vp(p), None, vp(p), None, 0, 128, 4096, 4096, 16, 0, None) == -7
     assert lib.awq_gemm_repacked_ws(None, 4096, vp(p), None, vp(p), None, 0, 1, 4096, 4096, 128, 0, None) == -1
-    # scratch is only ever wanted for 9 .. 32 rows of a supported fp16 layout on a narrow matrix
+    # scratch is wanted for 9 .. 32 rows of a supported fp16 layout on a narrow matrix (split-K GEMV) and from 33 rows where the MFMA
+    # tiling leaves most CUs idle (split-K tiles: up to 8 slices of M x N fp32, at most 32 MiB); never for one row, bf16, or many tiles
     assert lib.awq_gemm_repacked_workspace_bytes(1, 11008, 4096, 128, 0) == 0
-    assert lib.awq_gemm_repacked_workspace_bytes(64, 11008, 4096, 128, 0) == 0
+    assert lib.awq_gemm_repacked_workspace_bytes(64, 11008, 4096, 128, 0) == 4096 + 8 * 64 * 4096 * 4
+    assert lib.awq_gemm_repacked_workspace_bytes(512, 11008, 4096, 128, 0) == 4096 + 4 * 512 * 4096 * 4      # 32 MiB budget: 4 slices
+    assert lib.awq_gemm_repacked_workspace_bytes(2048, 4096, 11008, 128, 0) == 0                                # 688 tiles: no split
+    assert lib.awq_gemm_repacked_workspace_bytes(64, 11008, 4096, 128, 1) == 0
     assert lib.awq_gemm_repacked_workspace_bytes(32, 11008, 4096, 128, 1) == 0
     assert lib.awq_gemm_repacked_workspace_bytes(32, 4096, 22016, 128, 0) == 0
     assert 0 < lib.awq_gemm_repacked_workspace_bytes(32, 11008, 4096, 128, 0) <= 4096 + (32 << 20)
