@@ -156,7 +156,12 @@ int awq_gemm_ex(const void* x, int64_t ldx, const int32_t* qweight, const void* 
     void* packed = (char*)workspace + kWorkspaceHead;
     rc = launch_repack(qweight, scales, qzeros, packed, K, N, group_size, dtype, a.stream);
     if (rc) return rc;
-    return repacked_dispatch(a, packed);
+    // the re-laid-out copy occupies the front of the workspace: a route that wants scratch of its own (split-K tiles) gets what lies behind it
+    GemmArgs c = a;
+    const size_t used = (kWorkspaceHead + repacked_bytes(K, N, group_size) + 15) & ~(size_t)15;
+    c.workspace = workspace_bytes > used ? (char*)workspace + used : nullptr;
+    c.workspace_bytes = workspace_bytes > used ? workspace_bytes - used : 0;
+    return repacked_dispatch(c, packed);
   }
   // 16 < M <= 48: the 128-row tiles of the prefill kernel would leave most CUs idle (N / 128 workgroups);
   // two or three passes of the decode kernel over 16-row slabs of x are faster (measured 82 us tiled vs

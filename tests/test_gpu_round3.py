@@ -593,3 +593,23 @@ def test_split_k_tiles_vs_oracle(ops, M, K, N, g, bias):
     gph.replay()
     torch.cuda.synchronize()
     assert torch.equal(cap, y1) and torch.equal(warm, y1)
+
+
+@pytest.mark.parametrize("M,K,N", [(128, 11008, 4096), (96, 4096, 4096), (200, 2048, 1024)])
+def test_op_on_checkpoint_tensors_middle_rows_vs_oracle(ops, M, K, N):
+    """`sgl_kernel.awq_gemm` on checkpoint tensors, cache off, 33 rows and up: the op re-lays the weight out into the FRONT of its workspace
+    and then runs the fragment-major kernels — whose split-K tile route wants scratch of its own.  The two must not share bytes (the route
+    gets what lies behind the copy, or none): results against the oracle, and equal to the persistent-copy path."""
+    g = 128
+    qw, s, qz = synth.make_awq_weights(K, N, g, "f16", "A", seed=M + K)
+    x = synth.make_activations(M, K, "f16", "A", seed=M)
+    tq, ts, tz, tx = (to_torch(t, DEV) for t in (qw, s, qz, x))
+    ops.awq_gemm_cache_enable(False)
+    y_op = ops.awq_gemm(tx, tq, ts, tz, 1)
+    _, exact = c_oracle.gemm(x, qw, s, qz, want_exact=True)
+    assert_gemm_close(to_np(y_op), exact, "f16", what=f"op, on-the-fly re-layout, M={M} K={K} N={N}")
+    packed = ops.awq_repack(tq, ts, tz)
+    y_rp = ops.awq_gemm_repacked(tx, packed, K, N, g)
+    assert_gemm_close(to_np(y_rp), exact, "f16", what=f"persistent copy, M={M} K={K} N={N}")
+    # (the two may take different slice counts — the op's scratch is partly taken by the copy — so: equal up to fp32 summation order)
+    assert (y_op != y_rp).float().mean().item() < 0.05
