@@ -72,7 +72,7 @@ struct PfSplit {
 // A launch covers the column groups [cg_base, cg_base + ng_region) of the matrix; the host cuts N into a region of 256-wide
 // tiles that fills whole rounds of the 256 CUs and a remainder of 192-wide tiles, so that 2048 x 11008 costs 2 + 0.75 rounds
 // instead of the 3 that 688 equal tiles pay for 2.69 (launch_gemm_repacked_pipelined).
-template <int NJ, bool MOE = false, int EPI = 0, int MI = 8>
+template <int NJ, bool MOE = false, int EPI = 0, int MI = 8, bool SPLIT = false>
 __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(const uint16_t* __restrict__ x, int64_t ldx,
                                                                                 const u32x4_t* __restrict__ qw_r,
                                                                                 const uint32_t* __restrict__ zs_r,
@@ -90,12 +90,14 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
   const int q = lane >> 4, r = lane & 15;                          // an SGPR base + a 32-bit lane offset (no 64-bit VALU address math
   const int KBT = K / 128, groups = K / g, kpg = g / 128;          // in the loop: it is not hidden behind the MFMAs)
 
-  const int ntile = nbx * nby, nwg = ntile * split.S, bid = blockIdx.x;
+  // (SPLIT is a template parameter so that the unsplit instantiations compile exactly as before: the slice arithmetic, though a handful of
+  // scalar instructions, cost the dense prefill 1-2 %)
+  const int ntile = nbx * nby, nwg = SPLIT ? ntile * split.S : ntile, bid = blockIdx.x;
   const int xcd = bid & 7, qd = nwg >> 3, rem = nwg & 7;
   const int logical_all = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (bid >> 3);
-  const int slice = logical_all / ntile, logical = logical_all - slice * ntile;
-  const int k0 = slice * split.kb_per;                              // this workgroup's k-blocks: [k0, k0 + KB)
-  const int KB = split.S > 1 ? (KBT - k0 < split.kb_per ? KBT - k0 : split.kb_per) : KBT;
+  const int slice = SPLIT ? logical_all / ntile : 0, logical = SPLIT ? logical_all - slice * ntile : logical_all;
+  const int k0 = SPLIT ? slice * split.kb_per : 0;                  // this workgroup's k-blocks: [k0, k0 + KB)
+  const int KB = SPLIT ? (KBT - k0 < split.kb_per ? KBT - k0 : split.kb_per) : KBT;
   const int bm = (logical / nbx) * BM;
   const int cg_tile = cg_base + (logical % nbx) * (4 * NJ) + wn * NJ;       // this wave's first column group
   const int cg_end = cg_base + ng_region < NG ? cg_base + ng_region : NG;
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
           for (int j = 0; j < NJ; ++j) {
             const int n = (cg_tile + j) * 16 + r;
             if (cg_tile + j < cg_end && n < N) {
-              if (split.part != nullptr) split.part[((size_t)slice * M + m) * N + n] = acc[mi][j][i];       // (uniform)
+              if constexpr (SPLIT) split.part[((size_t)slice * M + m) * N + n] = acc[mi][j][i];
               else store_output<AWQ_DTYPE_F16>(y, (size_t)m * N + n, acc[mi][j][i], bias, n);
             }
           }
@@ -370,9 +372,9 @@ static int pf_launch_split(const GemmArgs& a, const u32x4_t* qw_r, const uint32_
   const int nbx = (NG + 4 * NJ - 1) / (4 * NJ), nby = (a.M + kPfBM - 1) / kPfBM;
   const size_t lds = 2 * kPfBM * 256;
   static unsigned long long opted[2] = {0ull, 0ull};
-  if (!opt_in_dynamic_lds((const void*)gemm_repacked_pipelined_kernel<NJ, false, 0, 8>, (int)lds, opted)) return AWQ_ERR_LAUNCH;
+  if (!opt_in_dynamic_lds((const void*)gemm_repacked_pipelined_kernel<NJ, false, 0, 8, true>, (int)lds, opted)) return AWQ_ERR_LAUNCH;
   float* part = (float*)((char*)a.workspace + kPfSplitHead);
-  hipLaunchKernelGGL((gemm_repacked_pipelined_kernel<NJ, false, 0, 8>), dim3(nbx * nby * S), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x,
+  hipLaunchKernelGGL((gemm_repacked_pipelined_kernel<NJ, false, 0, 8, true>), dim3(nbx * nby * S), dim3(kPfThreads), lds, a.stream, (const uint16_t*)a.x,
                      a.ldx, qw_r, zs_r, nullptr, a.y, a.M, a.K, a.N, a.g, NG, nbx, nby, 0, NG, PfMoe{nullptr, nullptr, nullptr, 0ll, 1},
                      PfSplit{part, S, kb_per});
   const size_t MN = (size_t)a.M * a.N;
