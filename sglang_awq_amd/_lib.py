@@ -33,7 +33,7 @@ EXPORTS = (
 AUX_EXPORTS = ("awq_aux_add_rmsnorm", "awq_aux_decode_attention", "awq_aux_decode_attention_workspace_bytes",
                "awq_aux_argmax_advance", "awq_aux_silu_mul",
                "awq_aux_gemv_repacked_fused", "awq_aux_moe_gemv", "awq_aux_moe_gemv_blocks", "awq_aux_moe_align_blocks",
-               "awq_aux_moe_align_blocks_n", "awq_aux_moe_gemm_blocks")
+               "awq_aux_moe_align_blocks_n", "awq_aux_moe_gemm_blocks", "awq_aux_moe_sum")
 ABI_VERSION = 2
 
 DTYPE_F16, DTYPE_BF16, DTYPE_F32 = 0, 1, 2
@@ -100,6 +100,8 @@ def _bind(L):
     L.awq_aux_moe_gemv_blocks.restype = ci
     L.awq_aux_moe_align_blocks.argtypes = [vp, i64, i64, vp, vp, i64, vp]
     L.awq_aux_moe_align_blocks.restype = ci
+    L.awq_aux_moe_sum.argtypes = [vp, vp, i64, i64, i64, vp]
+    L.awq_aux_moe_sum.restype = ci
     L.awq_aux_moe_align_blocks_n.argtypes = [vp, i64, i64, ci, vp, vp, i64, vp]
     L.awq_aux_moe_align_blocks_n.restype = ci
     L.awq_aux_moe_gemm_blocks.argtypes = [vp, i64, ci, vp, i64, vp, vp, i64, ci, vp, vp, i64, i64, i64, ci, ci, vp]

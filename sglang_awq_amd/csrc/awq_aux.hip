@@ -293,6 +293,24 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const half_t* __r
   }
 }
 
+// out[t, :] = fp16(sum over k of fp32(y[t * top_k + k, :]))   (the combine step of an MoE layer: the pairs' fp16 outputs added in fp32, one
+// rounding — what `y.view(T, top_k, K).sum(1, dtype=float32).half()` computes in two launches), K % 8 == 0
+__global__ __launch_bounds__(256) void moe_sum_kernel(const half_t* __restrict__ y, half_t* __restrict__ out, int top_k, int K, size_t total8) {
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < total8; v += (size_t)gridDim.x * blockDim.x) {
+    const size_t t = (v * 8) / K, c = (v * 8) % K;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < top_k; ++k) {
+      const half8v h = *(const half8v*)(y + (t * top_k + k) * K + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (float)h[e];
+    }
+    half8v o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)acc[e];
+    *(half8v*)(out + t * K + c) = o;
+  }
+}
+
 // act[b, i] = silu(gu[b, i]) * gu[b, I + i]   (SiluAndMul), I % 8 == 0
 __global__ __launch_bounds__(256) void silu_mul_kernel(const half_t* __restrict__ gu, half_t* __restrict__ act, int I, size_t total8) {
   for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < total8; v += (size_t)gridDim.x * blockDim.x) {
@@ -414,6 +432,17 @@ int awq_aux_argmax_advance(const void* logits, int64_t* tokens, int64_t* pos, in
   if (((uintptr_t)logits) & 15) return AWQ_ERR_MISALIGNED;
   hipLaunchKernelGGL(awq::argmax_advance_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, (const awq::half_t*)logits, tokens, pos,
                      (int)V);
+  return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
+
+int awq_aux_moe_sum(const void* y, void* out, int64_t tokens, int64_t top_k, int64_t K, void* stream) {
+  if (!y || !out) return AWQ_ERR_NULL_POINTER;
+  if (tokens <= 0 || top_k <= 0 || top_k > 1024 || K <= 0 || K % 8) return AWQ_ERR_BAD_SHAPE;
+  if ((((uintptr_t)y) | ((uintptr_t)out)) & 15) return AWQ_ERR_MISALIGNED;
+  const size_t total8 = (size_t)tokens * K / 8;
+  const unsigned grid = (unsigned)((total8 + 255) / 256 < 2048 ? (total8 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(awq::moe_sum_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const awq::half_t*)y, (awq::half_t*)out, (int)top_k, (int)K,
+                     total8);
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 

@@ -273,4 +273,10 @@ class AWQMoEMethod:
             y = self._moe_blocks(act, layer.w2_packed, row_map, block_expert, wts, pairs, 1, I, K, False)
             if y is None:
                 raise NotImplementedError(f"AWQMoEMethod: no kernel for experts K={K} I={I} group_size={self.quant_config.group_size}")
+        if K % 8 == 0:                                        # one launch: fp32 sum over each token's pairs, one rounding
+            out = torch.empty((T, K), dtype=torch.float16, device=x.device)
+            rc = _lib.load().awq_aux_moe_sum(ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(out.data_ptr()), T, top_k, K,
+                                             ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+            _lib.check(rc, "awq_aux_moe_sum")
+            return out
         return y.view(T, top_k, K).sum(dim=1, dtype=torch.float32).to(torch.float16)
