@@ -34,8 +34,11 @@ int awq_aux_decode_attention(const void* qkv, const int64_t* pos, const float* c
 int awq_aux_argmax_advance(const void* logits, int64_t* tokens, int64_t* pos, int64_t B, int64_t V, void* stream);
 
 /* out[tokens, K] = fp16(sum over k of fp32(y[tokens * top_k, K])): the combine step of an MoE layer over its (token, expert) pairs' outputs
- * (the reference's moe_sum_reduce, layers/moe/fused_moe_triton/fused_moe.py), one launch; fp16, K % 8 == 0, both 16-byte aligned. */
-int awq_aux_moe_sum(const void* y, void* out, int64_t tokens, int64_t top_k, int64_t K, void* stream);
+ * (the reference's moe_sum_reduce, layers/moe/fused_moe_triton/fused_moe.py), one launch; fp16, K % 8 == 0, both 16-byte aligned.
+ * expert_ids (may be NULL) [tokens * top_k]: pairs whose id lies outside [0, num_experts) — padded tokens — are skipped, so the rows of y
+ * the block / tile routes never write need no initialisation. */
+int awq_aux_moe_sum(const void* y, void* out, int64_t tokens, int64_t top_k, int64_t K, const int32_t* expert_ids, int64_t num_experts,
+                    void* stream);
 
 /* act[rows, I] = silu(gate_up[:, :I]) * gate_up[:, I:]   (layers/activation.py SiluAndMul) */
 int awq_aux_silu_mul(const void* gate_up, void* act, int64_t rows, int64_t I, void* stream);

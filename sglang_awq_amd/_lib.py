@@ -100,7 +100,7 @@ def _bind(L):
     L.awq_aux_moe_gemv_blocks.restype = ci
     L.awq_aux_moe_align_blocks.argtypes = [vp, i64, i64, vp, vp, i64, vp]
     L.awq_aux_moe_align_blocks.restype = ci
-    L.awq_aux_moe_sum.argtypes = [vp, vp, i64, i64, i64, vp]
+    L.awq_aux_moe_sum.argtypes = [vp, vp, i64, i64, i64, vp, i64, vp]
     L.awq_aux_moe_sum.restype = ci
     L.awq_aux_moe_align_blocks_n.argtypes = [vp, i64, i64, ci, vp, vp, i64, vp]
     L.awq_aux_moe_align_blocks_n.restype = ci

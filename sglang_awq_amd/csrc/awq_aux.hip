@@ -295,11 +295,17 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const half_t* __r
 
 // out[t, :] = fp16(sum over k of fp32(y[t * top_k + k, :]))   (the combine step of an MoE layer: the pairs' fp16 outputs added in fp32, one
 // rounding — what `y.view(T, top_k, K).sum(1, dtype=float32).half()` computes in two launches), K % 8 == 0
-__global__ __launch_bounds__(256) void moe_sum_kernel(const half_t* __restrict__ y, half_t* __restrict__ out, int top_k, int K, size_t total8) {
+// ids != nullptr: pairs whose expert id lies outside [0, num_experts) (padded tokens) are skipped — their rows of y need not be initialised.
+__global__ __launch_bounds__(256) void moe_sum_kernel(const half_t* __restrict__ y, half_t* __restrict__ out, int top_k, int K, size_t total8,
+                                                      const int* __restrict__ ids, int num_experts) {
   for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < total8; v += (size_t)gridDim.x * blockDim.x) {
     const size_t t = (v * 8) / K, c = (v * 8) % K;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < top_k; ++k) {
+      if (ids != nullptr) {
+        const int e = ids[t * top_k + k];
+        if (e < 0 || e >= num_experts) continue;
+      }
       const half8v h = *(const half8v*)(y + (t * top_k + k) * K + c);
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += (float)h[e];
@@ -435,14 +441,15 @@ int awq_aux_argmax_advance(const void* logits, int64_t* tokens, int64_t* pos, in
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
-int awq_aux_moe_sum(const void* y, void* out, int64_t tokens, int64_t top_k, int64_t K, void* stream) {
+int awq_aux_moe_sum(const void* y, void* out, int64_t tokens, int64_t top_k, int64_t K, const int32_t* expert_ids, int64_t num_experts,
+                    void* stream) {
   if (!y || !out) return AWQ_ERR_NULL_POINTER;
-  if (tokens <= 0 || top_k <= 0 || top_k > 1024 || K <= 0 || K % 8) return AWQ_ERR_BAD_SHAPE;
+  if (tokens <= 0 || top_k <= 0 || top_k > 1024 || K <= 0 || K % 8 || (expert_ids && (num_experts < 1 || num_experts > INT32_MAX))) return AWQ_ERR_BAD_SHAPE;
   if ((((uintptr_t)y) | ((uintptr_t)out)) & 15) return AWQ_ERR_MISALIGNED;
   const size_t total8 = (size_t)tokens * K / 8;
   const unsigned grid = (unsigned)((total8 + 255) / 256 < 2048 ? (total8 + 255) / 256 : 2048);
   hipLaunchKernelGGL(awq::moe_sum_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const awq::half_t*)y, (awq::half_t*)out, (int)top_k, (int)K,
-                     total8);
+                     total8, expert_ids, (int)num_experts);
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 

@@ -160,8 +160,10 @@ class AWQMoEMethod:
 
     def _moe_blocks(self, x, packed, row_map, block_expert, slot_scale, pairs, x_div, K, N, silu, tiles=0):
         g = self.quant_config.group_size
-        # rows of padded / dropped pairs are never written by the kernel: start from zeros so the top_k sum ignores them
-        y = torch.zeros((pairs, N // 2 if silu else N), dtype=torch.float16, device=x.device)
+        # rows of padded / dropped pairs are never written by the kernel: the combine launch skips them by expert id (no zero-fill launch);
+        # only the tensor-op fallback of the combine (K % 8 != 0) needs zeros
+        alloc = torch.empty if K % 8 == 0 and N % 8 == 0 else torch.zeros
+        y = alloc((pairs, N // 2 if silu else N), dtype=torch.float16, device=x.device)
         # tiles = 64 / 128: rows per block on the MFMA tile kernel; 0: 16-row blocks on the GEMV
         rows_arg = (int(tiles),) if tiles else ()
         fn = _lib.load().awq_aux_moe_gemm_blocks if tiles else _lib.load().awq_aux_moe_gemv_blocks
@@ -276,6 +278,7 @@ class AWQMoEMethod:
         if K % 8 == 0:                                        # one launch: fp32 sum over each token's pairs, one rounding
             out = torch.empty((T, K), dtype=torch.float16, device=x.device)
             rc = _lib.load().awq_aux_moe_sum(ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(out.data_ptr()), T, top_k, K,
+                                             ctypes.c_void_p(ids.data_ptr()), E,
                                              ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
             _lib.check(rc, "awq_aux_moe_sum")
             return out
