@@ -19,8 +19,8 @@
 //  33..160       while passes cost less than the tiles     passes of <= 32 rows of the GEMV                a pass 10.3 / 13.2 / 19.7 / 22.8 us on 4096 x 4096 / x 11008 / x 22016 /
 //                (gemv_passes_max: 2..4 passes)                                                           11008 x 4096; under-filled tiles ~1.12 us per k-block: 37-44 / 91 us
 //                                                                                                         (r03_kbench_middle_rows_ab.txt: 4096 x 22016 at 128 rows 78.6 -> 44)
-//  33..          few wide tiles, workspace given           gemm_repacked_pipelined_kernel with K split     11008 x 4096 at 128 / 256 rows 88.8 -> 28.6 / 88.9 -> 41.9; 8192 x 8192 at 128
-//                (pf_split_plan)                           over workgroups + pf_splitk_reduce_kernel       rows 76.2 -> 38.7; 4096 x 11008 at 96 / 128 rows 39.5 -> 30.0 / 38.6 -> 32.9
+//  33..          few wide tiles, workspace given           gemm_repacked_pipelined_kernel with K split     11008 x 4096 at 128 / 256 rows 88.7 -> 26.4 / 88.9 -> 40.5; 8192 x 8192 at 128
+//                (pf_split_plan)                           over workgroups + pf_splitk_reduce_kernel       rows 76.4 -> 35.2; 4096 x 11008 at 96 / 128 rows 40.4 -> 27.1 / 38.6 -> 28.2
 //                                                                                                         (r03_kbench_split_tiles_ab.txt)
 //  97..          <= 64 wide tiles, no workspace            gemm_repacked_ksplit_kernel (128 x 64 tiles)    11008 x 4096 at 256 / 512 rows 142 -> 90 / 97
 //  161..         any                                       gemm_repacked_pipelined_kernel: 128 x 256 tiles 2048 x 4096 x 11008: 206.6 -> 200.3 with the wide + narrow

@@ -288,6 +288,31 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
           }
         }
       }
+  } else if constexpr (SPLIT) {
+    // fp32 partial tile -> part[slice][M][N].  Straight from the accumulators a store instruction covers 4 rows x 64 bytes; through the
+    // (now idle) x buffers of LDS, wave-private, 64 rows at a time, every lane stores 16 bytes of a 256-byte (NJ = 4) or 128-byte row run.
+    static_assert(MI == 8, "two halves of 64 rows");
+    constexpr int WC = NJ * 16;                                   // columns of this wave
+    __syncthreads();                                              // every wave has read its last x fragments: the buffers are free
+    float* const tw = (float*)As + (size_t)wn * (64 * WC);        // 64 rows x WC floats: 16 KiB per wave at NJ = 4 (4 waves: the 64 KiB)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) tw[(mi * 16 + 4 * q + i) * WC + j * 16 + r] = acc[half * 4 + mi][j][i];
+      // (a wave's LDS accesses complete in order: no barrier between its own writes and reads)
+#pragma unroll
+      for (int p = 0; p < WC / 4; ++p) {
+        const int f = (p * 64 + lane) * 4;
+        const int row = f / WC, col = f - row * WC;
+        const int m = bm + half * 64 + row, cg = cg_tile + (col >> 4), n = cg * 16 + (col & 15);
+        const float4_t v = *(const float4_t*)(tw + f);
+        if (m < M && cg < cg_end && n < N) *(float4_t*)(split.part + ((size_t)slice * M + m) * N + n) = v;
+      }
+    }
   } else {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -298,10 +323,7 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
             const int n = (cg_tile + j) * 16 + r;
-            if (cg_tile + j < cg_end && n < N) {
-              if constexpr (SPLIT) split.part[((size_t)slice * M + m) * N + n] = acc[mi][j][i];
-              else store_output<AWQ_DTYPE_F16>(y, (size_t)m * N + n, acc[mi][j][i], bias, n);
-            }
+            if (cg_tile + j < cg_end && n < N) store_output<AWQ_DTYPE_F16>(y, (size_t)m * N + n, acc[mi][j][i], bias, n);
           }
         }
       }
