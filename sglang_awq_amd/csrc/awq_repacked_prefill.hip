@@ -44,6 +44,9 @@ __device__ __forceinline__ void dq_stage(DqPipe& p, half2_t z1024, half2_t z64, 
 #define PF_ABL 0            // diagnostic builds only (timing ablations; results are wrong): 1 no dequant stages, 2 no LDS fragment reads in the loop, 4 no x-tile loads / LDS writes, 8 no barrier
 #endif
 constexpr int kPfThreads = 256;
+#ifndef PF_LDS_EPILOGUE
+#define PF_LDS_EPILOGUE 1   // 0: A/B build, the output tile is stored straight from the accumulators (round 1-2 form)
+#endif
 
 // AWQ-MoE prefill (MOE = true; awq_aux_moe_gemm_blocks): the rows are (token, expert) pairs grouped by expert into 128-row blocks that
 // never straddle two experts (awq_aux_moe_align_blocks_n, the reference's moe_align_block_size step); a row tile takes its weights from
@@ -311,6 +314,41 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
         const int m = bm + half * 64 + row, cg = cg_tile + (col >> 4), n = cg * 16 + (col & 15);
         const float4_t v = *(const float4_t*)(tw + f);
         if (m < M && cg < cg_end && n < N) *(float4_t*)(split.part + ((size_t)slice * M + m) * N + n) = v;
+      }
+    }
+  } else if constexpr (MI == 8 && PF_LDS_EPILOGUE) {
+    // the same route for the fp16 output tile: rounded (and biased) exactly as store_output does, parked in the idle x buffers, stored as
+    // 16 bytes per lane (8 lanes per 128-byte row run of this wave's 64 columns; straight from the accumulators: 4 rows x 32 bytes a store)
+    constexpr int WC = NJ * 16;
+    __syncthreads();
+    half_t* const tw = (half_t*)As + (size_t)wn * (64 * WC);
+    const bool n_ok8 = (N % 8) == 0;                               // (16-byte stores need 8-column alignment; otherwise element stores below)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int n = (cg_tile + j) * 16 + r;
+            half_t h = (half_t)acc[half * 4 + mi][j][i];
+            if (bias && cg_tile + j < cg_end && n < N) h = h + ((const half_t*)bias)[n];
+            tw[(mi * 16 + 4 * q + i) * WC + j * 16 + r] = h;
+          }
+#pragma unroll
+      for (int p = 0; p < WC / 8; ++p) {
+        const int f = (p * 64 + lane) * 8;
+        const int row = f / WC, col = f - row * WC;
+        const int m = bm + half * 64 + row, cg = cg_tile + (col >> 4), n = cg * 16 + (col & 15);
+        if (m < M && cg < cg_end && n < N) {
+          if (n_ok8) {
+            *(u32x4_t*)((half_t*)y + (size_t)m * N + n) = *(const u32x4_t*)(tw + f);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (n + e < N) ((half_t*)y)[(size_t)m * N + n + e] = tw[f + e];
+          }
+        }
       }
     }
   } else {
