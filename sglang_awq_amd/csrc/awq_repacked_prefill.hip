@@ -266,31 +266,44 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results must have left the pipe before the (compiler-scheduled) reads below
 
   if constexpr (MOE) {
+    // values as the other routes round them (routed weight on the fp32 sums, SiLU-mul over the (gate, up) pairs of groups), parked wave-privately
+    // in the idle x buffers 64 rows at a time, then every lane stores 16 bytes of its pair's output row (rows scatter by pair index)
+    constexpr int WO = EPI == 1 ? NJ * 8 : NJ * 16;               // output columns of this wave
+    const int width = EPI == 1 ? N / 2 : N;
+    const int n_wave = EPI == 1 ? (cg_tile >> 1) * 16 : cg_tile * 16;         // first output column of this wave
+    __syncthreads();
+    half_t* const tw = (half_t*)As + (size_t)wn * (64 * WO);
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int half = 0; half < MI / 4; ++half) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int pr = moe.row_map[bm + mi * 16 + 4 * q + i];
-        if (pr < 0) continue;
-        const float sc = moe.slot_scale ? moe.slot_scale[pr] : 1.f;
-        if constexpr (EPI == 1) {
-          const int I = N / 2;
+      for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-          for (int j = 0; j < NJ; j += 2) {
-            const int n = ((cg_tile + j) >> 1) * 16 + r;
-            if (cg_tile + j + 1 < cg_end && n < I) {
-              const float xg = (float)(half_t)(acc[mi][j][i] * sc);       // the unfused path rounds gate_up to fp16 first
-              ((half_t*)y)[(size_t)pr * I + n] = (half_t)(xg / (1.f + __expf(-xg))) * (half_t)(acc[mi][j + 1][i] * sc);
+        for (int i = 0; i < 4; ++i) {
+          const int rl = mi * 16 + 4 * q + i;
+          const int pr = moe.row_map[bm + half * 64 + rl];
+          const float sc = (pr >= 0 && moe.slot_scale) ? moe.slot_scale[pr] : 1.f;
+          if constexpr (EPI == 1) {
+#pragma unroll
+            for (int j = 0; j < NJ; j += 2) {
+              const float xg = (float)(half_t)(acc[half * 4 + mi][j][i] * sc);       // the unfused path rounds gate_up to fp16 first
+              tw[rl * WO + (j >> 1) * 16 + r] = (half_t)(xg / (1.f + __expf(-xg))) * (half_t)(acc[half * 4 + mi][j + 1][i] * sc);
             }
-          }
-        } else {
+          } else {
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            const int n = (cg_tile + j) * 16 + r;
-            if (cg_tile + j < cg_end && n < N) store_output<AWQ_DTYPE_F16>(y, (size_t)pr * N + n, acc[mi][j][i] * sc, nullptr, n);
+            for (int j = 0; j < NJ; ++j) tw[rl * WO + j * 16 + r] = (half_t)(acc[half * 4 + mi][j][i] * sc);
           }
         }
+#pragma unroll
+      for (int p = 0; p < WO / 8; ++p) {
+        const int f = (p * 64 + lane) * 8;
+        const int row = f / WO, col = f - row * WO;
+        const int pr = moe.row_map[bm + half * 64 + row];
+        const int n = n_wave + col;
+        // (a 16-column output group is complete or absent: cg_end and N / width are multiples of what a group covers; width % 8 == 0)
+        const bool in = EPI == 1 ? (cg_tile + 2 * (col >> 4) + 1 < cg_end) : (cg_tile + (col >> 4) < cg_end);
+        if (pr >= 0 && in && n < width) *(u32x4_t*)((half_t*)y + (size_t)pr * width + n) = *(const u32x4_t*)(tw + f);
       }
+    }
   } else if constexpr (SPLIT) {
     // fp32 partial tile -> part[slice][M][N].  Straight from the accumulators a store instruction covers 4 rows x 64 bytes; through the
     // (now idle) x buffers of LDS, wave-private, 64 rows at a time, every lane stores 16 bytes of a 256-byte (NJ = 4) or 128-byte row run.
