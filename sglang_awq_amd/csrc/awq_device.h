@@ -124,6 +124,21 @@ __device__ __forceinline__ void store_output(void* y, size_t i, float v, const v
   }
 }
 
+// the 16-bit pattern store_output<DT> would write (DT = 0 fp16, 1 bf16): same operations, for epilogues that park a tile in LDS first
+template <int DT>
+__device__ __forceinline__ uint16_t output_bits16(float v, const void* bias, int n) {
+  static_assert(DT == 0 || DT == 1, "16-bit outputs");
+  if constexpr (DT == 0) {
+    half_t h = (half_t)v;
+    if (bias) h = h + ((const half_t*)bias)[n];
+    return __builtin_bit_cast(uint16_t, h);
+  } else {
+    float r = round_to_dtype<1>(v);
+    if (bias) r = round_to_dtype<1>(r + bf16_bits_to_float(((const uint16_t*)bias)[n]));
+    return float_to_bf16_bits(r);
+  }
+}
+
 // The 8 dequantised values of one packed word, each rounded to the storage dtype (as the reference
 // materialises W before its matmul, awq.py:446), returned as floats.  sc points at the 8 scales.
 template <int DT>

@@ -282,19 +282,53 @@ __global__ __launch_bounds__(256, 1) void gemm_rpx_tiled_kernel(const uint16_t* 
     }
     __syncthreads();
   }
+  // output tile through LDS (as awq_repacked_prefill.hip does): rounded (+ bias) as store_output<DT> would, parked wave-privately in the x
+  // buffers (every wave is past the loop's last barrier: nobody reads them any more), stored as 16 bytes per lane — 128-byte row runs
+  // instead of 4 rows x 32 bytes per store
+  if constexpr (DT == 0 || DT == 1) {
+    uint16_t* const tw = (uint16_t*)As + (size_t)wn * (64 * 64);
+    const bool n_ok8 = (N % 8) == 0;
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = bm + mi * 16 + 4 * q + i;
-      if (m < M) {
+      for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int n = bn + wn * 64 + j * 16 + r;
-          if (n < N) store_output<DT>(y, (size_t)m * N + n, acc[mi][j][i], bias, n);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int n = bn + wn * 64 + j * 16 + r;
+            tw[(mi * 16 + 4 * q + i) * 64 + j * 16 + r] = output_bits16<DT>(acc[half * 4 + mi][j][i], n < N ? bias : nullptr, n);
+          }
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int f = (p * 64 + lane) * 8;
+        const int row = f >> 6, col = f & 63;
+        const int m = bm + half * 64 + row, n = bn + wn * 64 + col;
+        if (m < M && n < N) {
+          if (n_ok8) {
+            *(u32x4_t*)((uint16_t*)y + (size_t)m * N + n) = *(const u32x4_t*)(tw + f);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (n + e < N) ((uint16_t*)y)[(size_t)m * N + n + e] = tw[f + e];
+          }
         }
       }
     }
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = bm + mi * 16 + 4 * q + i;
+        if (m < M) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int n = bn + wn * 64 + j * 16 + r;
+            if (n < N) store_output<DT>(y, (size_t)m * N + n, acc[mi][j][i], bias, n);
+          }
+        }
+      }
+  }
 }
 
 template <int DT, int GS>
