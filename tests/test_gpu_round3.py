@@ -613,3 +613,29 @@ def test_op_on_checkpoint_tensors_middle_rows_vs_oracle(ops, M, K, N):
     assert_gemm_close(to_np(y_rp), exact, "f16", what=f"persistent copy, M={M} K={K} N={N}")
     # (the two may take different slice counts — the op's scratch is partly taken by the copy — so: equal up to fp32 summation order)
     assert (y_op != y_rp).float().mean().item() < 0.05
+
+
+def test_moe_sum_matches_torch_and_skips_padded_pairs():
+    """awq_aux_moe_sum (the MoE combine: fp32 sum over each token's pairs, one rounding) against the two torch launches it replaces; pairs
+    whose expert id is outside [0, E) are skipped even when their rows hold NaN (the block / tile routes never write those rows)."""
+    lib = _lib.load()
+    T, top_k, K, E = 37, 6, 2048, 8
+    g = torch.Generator(device=DEV).manual_seed(3)
+    y = torch.randn(T * top_k, K, device=DEV, generator=g).half()
+    ids = torch.randint(0, E, (T * top_k,), device=DEV, generator=g, dtype=torch.int64).to(torch.int32)
+    ids[5] = -1; ids[6 * top_k:7 * top_k] = -1; ids[11] = E + 3
+    y[5] = float("nan"); y[6 * top_k:7 * top_k] = float("nan"); y[11] = float("inf")
+    out = torch.empty(T, K, dtype=torch.float16, device=DEV)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = lib.awq_aux_moe_sum(vp(y), vp(out), T, top_k, K, vp(ids), E, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    valid = ((ids >= 0) & (ids < E)).view(T, top_k, 1)
+    want = torch.where(valid, y.view(T, top_k, K).float(), torch.zeros((), device=DEV)).sum(dim=1)
+    got = out.float()
+    assert torch.isfinite(got).all() and torch.count_nonzero(got[6]) == 0
+    ulp = 2.0 ** (torch.floor(torch.log2(want.abs().clamp_min(2.0 ** -14))) - 10)
+    assert ((got - want).abs() <= 0.51 * ulp + 1e-6).all()               # one rounding of the fp32 sum (summation order may differ in the last fp32 bit)
+    out2 = torch.empty_like(out)
+    assert lib.awq_aux_moe_sum(vp(y[: T * top_k]), vp(out2), T, top_k, K, None, 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
+    assert torch.isnan(out2[0]).all() and torch.isnan(out2[6]).all()           # (without ids nothing is skipped: token 0 holds pair 5's NaN)
