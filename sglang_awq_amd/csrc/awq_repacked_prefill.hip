@@ -44,6 +44,9 @@ __device__ __forceinline__ void dq_stage(DqPipe& p, half2_t z1024, half2_t z64, 
 #define PF_ABL 0            // diagnostic builds only (timing ablations; results are wrong): 1 no dequant stages, 2 no LDS fragment reads in the loop, 4 no x-tile loads / LDS writes, 8 no barrier
 #endif
 constexpr int kPfThreads = 256;
+#ifndef PF_ROW_BLOCK
+#define PF_ROW_BLOCK 4      // row tiles per super-row of the 2-D blocked tile order (see the kernel); 0: A/B build, column tiles of a row tile consecutive
+#endif
 #ifndef PF_LDS_EPILOGUE
 #define PF_LDS_EPILOGUE 1   // 0: A/B build, the output tile is stored straight from the accumulators (round 1-2 form)
 #endif
@@ -101,8 +104,21 @@ __global__ __launch_bounds__(kPfThreads, 1) void gemm_repacked_pipelined_kernel(
   const int slice = SPLIT ? logical_all / ntile : 0, logical = SPLIT ? logical_all - slice * ntile : logical_all;
   const int k0 = SPLIT ? slice * split.kb_per : 0;                  // this workgroup's k-blocks: [k0, k0 + KB)
   const int KB = SPLIT ? (KBT - k0 < split.kb_per ? KBT - k0 : split.kb_per) : KBT;
-  const int bm = (logical / nbx) * BM;
-  const int cg_tile = cg_base + (logical % nbx) * (4 * NJ) + wn * NJ;       // this wave's first column group
+  // Tile order.  The workgroups an XCD runs together are 32 consecutive logical tiles.  As 32 column tiles of ONE row tile they share that row
+  // tile's x (1 MB at K = 4096) in the XCD's 4 MB L2 and stream 32 different weight tiles (16 MB) past it; ordered row-fastest inside
+  // super-rows of PF_ROW_BLOCK = 4 row tiles they cover 4 x 8 tiles: 4 MB of x and 4 MB of weights, each shared.  2048 x 11008 x 4096:
+  // 185.0 -> 183.5 us, M = 4096 360 -> 352, M = 8192 690 -> 666 (1.11 PFLOP/s); never slower (profiles/r03_kbench_prefill_tile_order_ab.txt).
+  // (The MoE and split-K launches keep the plain order: their row tiles belong to different experts / they have few tiles.)
+  int bm, cg_tile;
+  if constexpr (!MOE && !SPLIT && PF_ROW_BLOCK > 1) {
+    const int sb_tiles = PF_ROW_BLOCK * nbx, sb = logical / sb_tiles, in_sb = logical - sb * sb_tiles;
+    const int rows_sb = nby - sb * PF_ROW_BLOCK < PF_ROW_BLOCK ? nby - sb * PF_ROW_BLOCK : PF_ROW_BLOCK;
+    bm = (sb * PF_ROW_BLOCK + in_sb % rows_sb) * BM;
+    cg_tile = cg_base + (in_sb / rows_sb) * (4 * NJ) + wn * NJ;
+  } else {
+    bm = (logical / nbx) * BM;
+    cg_tile = cg_base + (logical % nbx) * (4 * NJ) + wn * NJ;       // this wave's first column group
+  }
   const int cg_end = cg_base + ng_region < NG ? cg_base + ng_region : NG;
   if constexpr (MOE) {
     const int eid = moe.block_expert[bm / BM];                  // uniform over the workgroup, read before any barrier
